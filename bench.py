@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="trajectories per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU oracle for cpu_baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = automatic: 128 for large batches)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="also time the CPU oracle with this many threads (one trajectory per thread; context only)")
     args = ap.parse_args()
 
@@ -82,6 +83,8 @@ def main():
     probs = scenes.random_problems(args.batch, seed0=1000 + rank * args.batch, occ_r2=m.occ_r2_buffer,
                                    grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
     opt = U.ALMTrajOpt(m)
+    if args.lanes:
+        opt.set_lanes(args.lanes)
     opt.upload(probs)          # inputs resident in HBM from here on
 
     def barrier():

@@ -145,15 +145,12 @@ int uph_ctx_create(uph_map* m, const uph_opt_params* p, uph_ctx** out);
 void uph_ctx_destroy(uph_ctx* c);
 /* rho is a member that persists across solves in the reference (alm_traj_opt.cpp:16, alm_traj_opt.h:137): every problem of a
  * batch starts from the context's rho; after a batch the context's rho becomes the final rho of the LAST problem. */
-/* lanes of one workgroup that cooperate on ONE trajectory: 64 (one wave64) or 256 (four waves; default = 0).  With 256 lanes,
- * batches of >= 512 problems use the register-capped build that lets two workgroups share a CU.  Results do not depend on
- * the choice beyond rounding order. */
+/* lanes of one workgroup that cooperate on ONE trajectory: 64, 128 or 256 (one, two or four wave64); 0 = automatic (default):
+ * 128 lanes with up to four workgroups per CU from 2304 problems (throughput), 256 lanes below (latency).  Takes effect at the next
+ * upload.  Results do not depend on the choice beyond the summation order of the block reductions. */
 int uph_ctx_set_lanes(uph_ctx* c, int32_t lanes);
 /* experiment knob: 2 = register-capped kernel build (two waves per SIMD), 1 = uncapped, 0 = choose from the batch size */
 int uph_ctx_set_wps(uph_ctx* c, int32_t wps);
-/* L-BFGS direction d = -H g: 1 = compact (Byrd-Nocedal-Schnabel) representation -- two parallel passes over the history and two
- * small triangular solves, algebraically identical to lbfgs.hpp:687-710 (default); 0 = the two-loop recursion itself */
-int uph_ctx_set_direction(uph_ctx* c, int32_t compact);
 int uph_ctx_set_rho(uph_ctx* c, double rho);
 int uph_ctx_get_rho(uph_ctx* c, double* rho);
 
@@ -176,7 +173,7 @@ int uph_batch_stats(uph_ctx* c, double* kernel_ms, int64_t* evals, int64_t* samp
  * this returns the kernel milliseconds of the former */
 int uph_batch_prepare_ms(uph_ctx* c, double* ms);
 
-/* diagnostic: shader-clock cycles per phase of the last uph_batch_solve, out[B][8]:
+/* diagnostic: shader-clock cycles per phase of the last uph_batch_solve, out[B][16]:
  * 0 MINCO generate, 1 constraint samples, 2 per-piece scatter, 3 adjoint, 4 L-BFGS two-loop, 5 initScaling, 6 whole solve */
 int uph_batch_cycles(uph_ctx* c, long long* out);
 

@@ -48,6 +48,19 @@ struct AlmTrajOpt {
     AlmStats stats;
     std::vector<double> trace;     // (test aid) fx after every accepted L-BFGS iteration, -1 marks an ALM pass boundary
     bool flat_debug = false;                  // the commented "debug" block cpp:787-803 (flat terrain)
+    // ---- TEST AIDS for the teacher-forced late-state tests (no effect on the algorithm)
+    struct PassRec {                          // one ALM pass: what went in, what came out
+        Vec x_in, lambda_in, mu_in, x_out, lambda_out, mu_out, hx, gx;
+        double rho_in = 0, rho_out = 0, cost = 0;
+        int ret = 0, k = 0, converged = 0;
+    };
+    bool record_passes = false;
+    std::vector<PassRec> passes;
+    std::vector<LbfgsIterLog> iter_log;       // every completed L-BFGS iteration of the last solve ...
+    std::vector<int> pass_log_start;          // ... and where each ALM pass starts in it
+    int snap_pass = -1, snap_k = -1;          // capture the L-BFGS state at the top of iteration snap_k of ALM pass snap_pass
+    bool snap_valid = false;
+    LbfgsState snap_state;
 
     explicit AlmTrajOpt(const AlmParams& pp = AlmParams()) : p(pp), rho(pp.rho) {}
 
@@ -547,27 +560,75 @@ struct AlmTrajOpt {
         if (p.use_scaling) initScaling(x);
         EvalFn eval = [this](const Vec& xx, Vec& gg) { return innerCallback(xx, gg); };
         ProgressFn prog = [this](const Vec&, const Vec&, double fx, double, int k, int) { trace.push_back(fx); return (int)(k > 1e3); };   // earlyExit :1016
+        passes.clear(); iter_log.clear(); pass_log_start.clear(); snap_valid = false;
+        int pass = 0;
         while (true) {                                                            // :234-271
             LbfgsStats ls;
             trace.push_back(-1.0);
-            int result = lbfgs_optimize(x, inner_cost, eval, prog, lp, &ls);
+            PassRec pr;
+            if (record_passes) { pr.x_in = x; pr.lambda_in = lambda; pr.mu_in = mu; pr.rho_in = rho; }
+            pass_log_start.push_back((int)iter_log.size());
+            LbfgsState snap;
+            const bool want = pass == snap_pass && !snap_valid;
+            int result = lbfgs_optimize(x, inner_cost, eval, prog, lp, &ls, want ? &snap : nullptr, want ? snap_k : -1, &iter_log);
+            if (want && !snap.x.empty()) { snap_state = snap; snap_valid = true; }
             stats.lbfgs_iters += ls.iters;
             stats.evals += ls.evals;
             stats.last_lbfgs_ret = result;
+            bool stop = false;
             if (result == LBFGS_CONVERGENCE || result == LBFGS_CANCELED || result == LBFGS_STOP || result == LBFGSERR_MAXIMUMITERATION) {
             } else if (result == LBFGSERR_MAXIMUMLINESEARCH) {
             } else {
                 ret_code = 1;
-                break;
+                stop = true;
             }
-            updateDualVars();                                                     // :257
-            if (judgeConvergence()) break;                                        // :259
+            bool conv = false;
+            if (!stop) {
+                updateDualVars();                                                 // :257
+                conv = judgeConvergence();                                        // :259
+            }
+            if (record_passes) {
+                pr.x_out = x; pr.lambda_out = lambda; pr.mu_out = mu; pr.rho_out = rho; pr.hx = hx; pr.gx = gx;
+                pr.cost = inner_cost; pr.ret = result; pr.k = ls.iters; pr.converged = conv ? 1 : 0;
+                passes.push_back(pr);
+            }
+            pass++;
+            if (stop) break;
+            if (conv) break;
             if (++iter > p.max_iter) { ret_code = 2; break; }                     // :265
         }
         stats.alm_iters = iter;
         stats.inner_cost = inner_cost;
         if (x_out) *x_out = x;
         return ret_code;
+    }
+
+    // ---- TEST AIDS: continue the L-BFGS iteration loop from a given state for at most `budget` iterations, with the object's current
+    // duals / scales / rho (set_state); and ONE complete ALM pass (lbfgs_optimize + updateDualVars + judgeConvergence) from x.
+    LbfgsParam lbfgsParams() const {
+        LbfgsParam lp;                                                            // :219-225
+        lp.mem_size = p.mem_size; lp.past = p.past; lp.g_epsilon = p.g_epsilon; lp.min_step = p.min_step; lp.delta = p.delta;
+        lp.max_iterations = (int)p.inner_max_iter;
+        return lp;
+    }
+    int lbfgsResume(LbfgsState& s, int budget) {
+        EvalFn eval = [this](const Vec& xx, Vec& gg) { return innerCallback(xx, gg); };
+        ProgressFn prog = [](const Vec&, const Vec&, double, double, int k, int) { return (int)(k > 1e3); };
+        LbfgsStats ls;
+        return lbfgs_loop(s, eval, prog, lbfgsParams(), &ls, budget, nullptr, -1, nullptr);
+    }
+    // returns the L-BFGS code; *accepted = the ALM accepted it (dual update + convergence test ran), *converged = judgeConvergence()
+    int almPass(Vec& x, double& cost, int& k, int& accepted, int& converged) {
+        EvalFn eval = [this](const Vec& xx, Vec& gg) { return innerCallback(xx, gg); };
+        ProgressFn prog = [](const Vec&, const Vec&, double, double, int kk, int) { return (int)(kk > 1e3); };
+        LbfgsStats ls;
+        const int result = lbfgs_optimize(x, cost, eval, prog, lbfgsParams(), &ls);
+        k = ls.iters;
+        accepted = (result == LBFGS_CONVERGENCE || result == LBFGS_CANCELED || result == LBFGS_STOP || result == LBFGSERR_MAXIMUMITERATION ||
+                    result == LBFGSERR_MAXIMUMLINESEARCH) ? 1 : 0;
+        converged = 0;
+        if (accepted) { updateDualVars(); converged = judgeConvergence() ? 1 : 0; }
+        return result;
     }
 
     // ---- post-solve report: getMaxVxAxAyCurAttSig h:170-229 + getNonHolError se2traj.hpp:551-561.

@@ -106,10 +106,100 @@ inline int line_search_lewisoverton(Vec& x, double& f, Vec& g, double& stp, cons
     }
 }
 
-inline int lbfgs_optimize(Vec& x, double& f, const EvalFn& eval, const ProgressFn& progress, const LbfgsParam& param, LbfgsStats* st) {
-    int ret, i, j, k = 0, ls, end, bound;
-    double step, step_min, step_max, fx, ys, yy;
-    double gnorm_inf, xnorm_inf, beta, rate, cau;
+// Complete state of lbfgs_optimize at the top of its iteration loop (lbfgs.hpp:555), i.e. just before `xp = x; gp = g`.
+// TEST AID (teacher-forced late-state tests): lets a test capture the state at a chosen iteration and lets both this
+// restatement and the device continue from exactly that state for a bounded number of iterations.
+struct LbfgsState {
+    Vec x, g, d, pf, lm_ys;
+    std::vector<double> lm_s, lm_y;     // column j at [j*n, (j+1)*n)
+    double step = 0.0, fx = 0.0;
+    int k = 0, end = 0, bound = 0;
+};
+struct LbfgsIterLog { int k, ls, bound, end, updated; };   // one record per completed iteration: ls = line-search return, updated = cautious test passed
+constexpr int LBFGS_RUNNING = 999;      // lbfgs_loop stopped by its iteration budget (not a reference code)
+
+// The iteration loop of lbfgs_optimize (lbfgs.hpp:555-715), continuing from `s`.  budget < 0: unlimited (the reference's behaviour);
+// otherwise at most `budget` iterations are executed and LBFGS_RUNNING is returned with `s` at the next loop top.
+// snap/snap_k: copy the state into *snap when the loop top is reached with k == snap_k.
+inline int lbfgs_loop(LbfgsState& s, const EvalFn& eval, const ProgressFn& progress, const LbfgsParam& param, LbfgsStats* st,
+                      int budget, LbfgsState* snap, int snap_k, std::vector<LbfgsIterLog>* log) {
+    int ret, i, j, ls;
+    double step_min, step_max, ys, yy, beta, rate, cau, gnorm_inf, xnorm_inf;
+    Vec& x = s.x; Vec& g = s.g; Vec& d = s.d; Vec& pf = s.pf; Vec& lm_ys = s.lm_ys;
+    std::vector<double>& lm_s = s.lm_s; std::vector<double>& lm_y = s.lm_y;
+    double& step = s.step; double& fx = s.fx; int& k = s.k; int& end = s.end; int& bound = s.bound;
+    const int n = (int)x.size();
+    const int m = param.mem_size;
+    Vec xp(n), gp(n), lm_alpha(m, 0.0);
+    while (true) {
+        if (snap && k == snap_k) *snap = s;
+        if (budget == 0) return LBFGS_RUNNING;
+        if (budget > 0) budget--;
+        xp = x; gp = g;                                       // :557-558
+        step_min = param.min_step;                            // :561-568 (no stepbound callback in the reference's call)
+        step_max = param.max_step;
+        ls = line_search_lewisoverton(x, fx, g, step, d, xp, gp, step_min, step_max, eval, param, st);   // :571
+        if (ls < 0) {                                         // :573-580
+            x = xp; g = gp;
+            ret = ls;
+            if (log) log->push_back({k, ls, bound, end, 0});
+            break;
+        }
+        if (progress) {                                       // :583-590
+            if (progress(x, g, fx, step, k, ls)) { ret = LBFGS_CANCELED; break; }
+        }
+        gnorm_inf = vabsmax(g);                               // :597-604
+        xnorm_inf = vabsmax(x);
+        if (gnorm_inf / std::max(1.0, xnorm_inf) < param.g_epsilon) { ret = LBFGS_CONVERGENCE; break; }
+        if (0 < param.past) {                                 // :611-628
+            if (param.past <= k) {
+                rate = std::fabs(pf[k % param.past] - fx) / std::max(1.0, std::fabs(fx));
+                if (rate < param.delta) { ret = LBFGS_STOP; break; }
+            }
+            pf[k % param.past] = fx;
+        }
+        if (param.max_iterations != 0 && param.max_iterations <= k) { ret = LBFGSERR_MAXIMUMITERATION; break; }   // :630-635
+        ++k;                                                  // :638
+        double* sc = &lm_s[(size_t)end * n];
+        double* yc = &lm_y[(size_t)end * n];
+        for (i = 0; i < n; i++) { sc[i] = x[i] - xp[i]; yc[i] = g[i] - gp[i]; }   // :645-646
+        ys = vdotp(yc, sc, n);                                // :654-656
+        yy = vdotp(yc, yc, n);
+        lm_ys[end] = ys;
+        for (i = 0; i < n; i++) d[i] = -g[i];                 // :659
+        cau = vdotp(sc, sc, n) * std::sqrt(vdot(gp, gp)) * param.cautious_factor;   // :673
+        if (log) log->push_back({k - 1, ls, bound, end, ys > cau ? 1 : 0});
+        if (ys > cau) {                                       // :675-708
+            ++bound;
+            bound = m < bound ? m : bound;
+            end = (end + 1) % m;
+            j = end;
+            for (i = 0; i < bound; ++i) {
+                j = (j + m - 1) % m;
+                lm_alpha[j] = vdotp(&lm_s[(size_t)j * n], d.data(), n) / lm_ys[j];
+                const double a = -lm_alpha[j];
+                const double* yj = &lm_y[(size_t)j * n];
+                for (int t = 0; t < n; t++) d[t] += a * yj[t];
+            }
+            const double sc0 = ys / yy;
+            for (int t = 0; t < n; t++) d[t] *= sc0;
+            for (i = 0; i < bound; ++i) {
+                beta = vdotp(&lm_y[(size_t)j * n], d.data(), n) / lm_ys[j];
+                const double a = lm_alpha[j] - beta;
+                const double* sj = &lm_s[(size_t)j * n];
+                for (int t = 0; t < n; t++) d[t] += a * sj[t];
+                j = (j + 1) % m;
+            }
+        }
+        step = 1.0;                                           // :712
+    }
+    return ret;
+}
+
+inline int lbfgs_optimize(Vec& x, double& f, const EvalFn& eval, const ProgressFn& progress, const LbfgsParam& param, LbfgsStats* st,
+                          LbfgsState* snap = nullptr, int snap_k = -1, std::vector<LbfgsIterLog>* log = nullptr) {
+    int ret, i;
+    double gnorm_inf, xnorm_inf;
     const int n = (int)x.size();
     const int m = param.mem_size;
     if (n <= 0) return LBFGSERR_INVALID_N;                         // :455-498
@@ -124,81 +214,27 @@ inline int lbfgs_optimize(Vec& x, double& f, const EvalFn& eval, const ProgressF
     if (!(param.machine_prec > 0.0)) return LBFGSERR_INVALID_MACHINEPREC;
     if (param.max_linesearch <= 0) return LBFGSERR_INVALID_MAXLINESEARCH;
 
-    Vec xp(n), g(n), gp(n), d(n), pf(std::max(1, param.past));   // :501-505
-    Vec lm_alpha(m, 0.0), lm_ys(m, 0.0);                          // :508-511
-    std::vector<double> lm_s((size_t)n * m, 0.0), lm_y((size_t)n * m, 0.0);   // column j at [j*n, (j+1)*n)
+    LbfgsState s;                                                  // :501-511 (xp, gp, lm_alpha are scratch of the loop)
+    s.x = x; s.g.assign(n, 0.0); s.d.assign(n, 0.0); s.pf.assign(std::max(1, param.past), 0.0);
+    s.lm_ys.assign(m, 0.0);
+    s.lm_s.assign((size_t)n * m, 0.0); s.lm_y.assign((size_t)n * m, 0.0);
 
-    fx = eval(x, g);                                              // :521
+    s.fx = eval(s.x, s.g);                                        // :521
     if (st) st->evals++;
-    pf[0] = fx;                                                   // :524
-    for (i = 0; i < n; i++) d[i] = -g[i];                         // :530
-    gnorm_inf = vabsmax(g);                                       // :535-536
-    xnorm_inf = vabsmax(x);
+    s.pf[0] = s.fx;                                               // :524
+    for (i = 0; i < n; i++) s.d[i] = -s.g[i];                     // :530
+    gnorm_inf = vabsmax(s.g);                                     // :535-536
+    xnorm_inf = vabsmax(s.x);
     if (gnorm_inf / std::max(1.0, xnorm_inf) < param.g_epsilon) { // :538-542
         ret = LBFGS_CONVERGENCE;
     } else {
-        step = 1.0 / std::sqrt(vdot(d, d));                       // :548
-        k = 1; end = 0; bound = 0;
-        while (true) {
-            xp = x; gp = g;                                       // :557-558
-            step_min = param.min_step;                            // :561-568 (no stepbound callback in the reference's call)
-            step_max = param.max_step;
-            ls = line_search_lewisoverton(x, fx, g, step, d, xp, gp, step_min, step_max, eval, param, st);   // :571
-            if (ls < 0) {                                         // :573-580
-                x = xp; g = gp;
-                ret = ls;
-                break;
-            }
-            if (progress) {                                       // :583-590
-                if (progress(x, g, fx, step, k, ls)) { ret = LBFGS_CANCELED; break; }
-            }
-            gnorm_inf = vabsmax(g);                               // :597-604
-            xnorm_inf = vabsmax(x);
-            if (gnorm_inf / std::max(1.0, xnorm_inf) < param.g_epsilon) { ret = LBFGS_CONVERGENCE; break; }
-            if (0 < param.past) {                                 // :611-628
-                if (param.past <= k) {
-                    rate = std::fabs(pf[k % param.past] - fx) / std::max(1.0, std::fabs(fx));
-                    if (rate < param.delta) { ret = LBFGS_STOP; break; }
-                }
-                pf[k % param.past] = fx;
-            }
-            if (param.max_iterations != 0 && param.max_iterations <= k) { ret = LBFGSERR_MAXIMUMITERATION; break; }   // :630-635
-            ++k;                                                  // :638
-            double* sc = &lm_s[(size_t)end * n];
-            double* yc = &lm_y[(size_t)end * n];
-            for (i = 0; i < n; i++) { sc[i] = x[i] - xp[i]; yc[i] = g[i] - gp[i]; }   // :645-646
-            ys = vdotp(yc, sc, n);                                // :654-656
-            yy = vdotp(yc, yc, n);
-            lm_ys[end] = ys;
-            for (i = 0; i < n; i++) d[i] = -g[i];                 // :659
-            cau = vdotp(sc, sc, n) * std::sqrt(vdot(gp, gp)) * param.cautious_factor;   // :673
-            if (ys > cau) {                                       // :675-708
-                ++bound;
-                bound = m < bound ? m : bound;
-                end = (end + 1) % m;
-                j = end;
-                for (i = 0; i < bound; ++i) {
-                    j = (j + m - 1) % m;
-                    lm_alpha[j] = vdotp(&lm_s[(size_t)j * n], d.data(), n) / lm_ys[j];
-                    const double a = -lm_alpha[j];
-                    const double* yj = &lm_y[(size_t)j * n];
-                    for (int t = 0; t < n; t++) d[t] += a * yj[t];
-                }
-                const double sc0 = ys / yy;
-                for (int t = 0; t < n; t++) d[t] *= sc0;
-                for (i = 0; i < bound; ++i) {
-                    beta = vdotp(&lm_y[(size_t)j * n], d.data(), n) / lm_ys[j];
-                    const double a = lm_alpha[j] - beta;
-                    const double* sj = &lm_s[(size_t)j * n];
-                    for (int t = 0; t < n; t++) d[t] += a * sj[t];
-                    j = (j + 1) % m;
-                }
-            }
-            step = 1.0;                                           // :712
-        }
+        s.step = 1.0 / std::sqrt(vdot(s.d, s.d));                 // :548
+        s.k = 1; s.end = 0; s.bound = 0;
+        ret = lbfgs_loop(s, eval, progress, param, st, -1, snap, snap_k, log);
     }
-    f = fx;                                                       // :717
-    if (st) st->iters = k;
+    x = s.x;
+    f = s.fx;                                                     // :717
+    if (st) st->iters = s.k;
     return ret;
 }
 

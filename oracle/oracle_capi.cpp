@@ -233,6 +233,85 @@ int orc_alm_optimize(void* h, const double* init_xy, const double* end_xy, const
     }
     return ret;
 }
+// ---------------- teacher-forced test aids
+// request an L-BFGS state capture at the top of iteration `k` of ALM pass `pass` (0-based) during the next orc_alm_optimize; record passes
+void orc_alm_set_capture(void* h, int pass, int k, int record_passes) {
+    AlmTrajOpt& a = ((OrcAlm*)h)->opt;
+    a.snap_pass = pass; a.snap_k = k; a.record_passes = record_passes != 0;
+}
+// iteration log of the last solve: rows of 6 ints {pass, k, ls, bound, end, updated}; returns the number of rows available
+int orc_alm_get_iter_log(void* h, int* out, int cap_rows) {
+    const AlmTrajOpt& a = ((OrcAlm*)h)->opt;
+    int pass = 0;
+    const int n = (int)a.iter_log.size();
+    for (int i = 0; i < n && i < cap_rows; i++) {
+        while (pass + 1 < (int)a.pass_log_start.size() && a.pass_log_start[pass + 1] <= i) pass++;
+        const LbfgsIterLog& r = a.iter_log[i];
+        out[6 * i] = pass; out[6 * i + 1] = r.k; out[6 * i + 2] = r.ls; out[6 * i + 3] = r.bound; out[6 * i + 4] = r.end; out[6 * i + 5] = r.updated;
+    }
+    return n;
+}
+// L-BFGS state: vectors x, g, d [n], pf [past], lm_ys [m], lm_s / lm_y [m*n] (slot j at j*n), scal = {step, fx, k, end, bound}
+static void stateOut(const LbfgsState& s, double* x, double* g, double* d, double* pf, double* lm_ys, double* lm_s, double* lm_y, double* scal) {
+    const size_t n = s.x.size();
+    if (x) std::memcpy(x, s.x.data(), 8 * n);
+    if (g) std::memcpy(g, s.g.data(), 8 * n);
+    if (d) std::memcpy(d, s.d.data(), 8 * n);
+    if (pf) std::memcpy(pf, s.pf.data(), 8 * s.pf.size());
+    if (lm_ys) std::memcpy(lm_ys, s.lm_ys.data(), 8 * s.lm_ys.size());
+    if (lm_s) std::memcpy(lm_s, s.lm_s.data(), 8 * s.lm_s.size());
+    if (lm_y) std::memcpy(lm_y, s.lm_y.data(), 8 * s.lm_y.size());
+    if (scal) { scal[0] = s.step; scal[1] = s.fx; scal[2] = s.k; scal[3] = s.end; scal[4] = s.bound; }
+}
+// captured state of the last solve (returns 0 if the requested iteration was never reached) + the duals / rho in force during that pass
+int orc_alm_get_capture(void* h, double* x, double* g, double* d, double* pf, double* lm_ys, double* lm_s, double* lm_y, double* scal,
+                        double* lambda, double* mu, double* rho) {
+    const AlmTrajOpt& a = ((OrcAlm*)h)->opt;
+    if (!a.snap_valid) return 0;
+    stateOut(a.snap_state, x, g, d, pf, lm_ys, lm_s, lm_y, scal);
+    if (a.record_passes && a.snap_pass < (int)a.passes.size()) {
+        const AlmTrajOpt::PassRec& pr = a.passes[a.snap_pass];
+        if (lambda) std::memcpy(lambda, pr.lambda_in.data(), 8 * pr.lambda_in.size());
+        if (mu) std::memcpy(mu, pr.mu_in.data(), 8 * pr.mu_in.size());
+        if (rho) *rho = pr.rho_in;
+    }
+    return 1;
+}
+// continue the iteration loop from the given state for at most `budget` iterations with the object's current duals / scales / rho;
+// the state is updated in place; returns the L-BFGS code or 999 (LBFGS_RUNNING) when the budget ran out first
+int orc_alm_lbfgs_resume(void* h, int n, double* x, double* g, double* d, double* pf, double* lm_ys, double* lm_s, double* lm_y, double* scal, int budget) {
+    AlmTrajOpt& a = ((OrcAlm*)h)->opt;
+    const int m = a.p.mem_size, past = std::max(1, a.p.past);
+    LbfgsState s;
+    s.x.assign(x, x + n); s.g.assign(g, g + n); s.d.assign(d, d + n); s.pf.assign(pf, pf + past); s.lm_ys.assign(lm_ys, lm_ys + m);
+    s.lm_s.assign(lm_s, lm_s + (size_t)m * n); s.lm_y.assign(lm_y, lm_y + (size_t)m * n);
+    s.step = scal[0]; s.fx = scal[1]; s.k = (int)scal[2]; s.end = (int)scal[3]; s.bound = (int)scal[4];
+    const int ret = a.lbfgsResume(s, budget);
+    stateOut(s, x, g, d, pf, lm_ys, lm_s, lm_y, scal);
+    return ret;
+}
+// number of recorded passes; pass record i: x_in/x_out [n], lambda_in/out [S], mu_in/out [6S], hx [S], gx [6S], scal = {rho_in, rho_out, cost, ret, k, converged}
+int orc_alm_num_passes(void* h) { return (int)((OrcAlm*)h)->opt.passes.size(); }
+int orc_alm_get_pass(void* h, int i, double* x_in, double* x_out, double* lambda_in, double* lambda_out, double* mu_in, double* mu_out, double* hx, double* gx, double* scal) {
+    const AlmTrajOpt& a = ((OrcAlm*)h)->opt;
+    if (i < 0 || i >= (int)a.passes.size()) return -1;
+    const AlmTrajOpt::PassRec& r = a.passes[i];
+    auto cp = [](double* dst, const Vec& v) { if (dst) std::memcpy(dst, v.data(), 8 * v.size()); };
+    cp(x_in, r.x_in); cp(x_out, r.x_out); cp(lambda_in, r.lambda_in); cp(lambda_out, r.lambda_out); cp(mu_in, r.mu_in); cp(mu_out, r.mu_out); cp(hx, r.hx); cp(gx, r.gx);
+    if (scal) { scal[0] = r.rho_in; scal[1] = r.rho_out; scal[2] = r.cost; scal[3] = r.ret; scal[4] = r.k; scal[5] = r.converged; }
+    return 0;
+}
+// ONE ALM pass from x with the object's current duals / scales / rho: lbfgs_optimize, then (if the ALM accepts the code) updateDualVars and
+// judgeConvergence.  out = {lbfgs code, k, accepted, converged, cost}
+void orc_alm_pass(void* h, int n, double* x, double* out5) {
+    AlmTrajOpt& a = ((OrcAlm*)h)->opt;
+    Vec xv(x, x + n);
+    double cost = 0; int k = 0, acc = 0, conv = 0;
+    const int ret = a.almPass(xv, cost, k, acc, conv);
+    std::memcpy(x, xv.data(), 8 * n);
+    out5[0] = ret; out5[1] = k; out5[2] = acc; out5[3] = conv; out5[4] = cost;
+}
+
 int orc_alm_get_trace(void* h, double* out, int cap) {
     const Vec& t = ((OrcAlm*)h)->opt.trace;
     int n = (int)std::min<size_t>(t.size(), (size_t)cap);

@@ -80,6 +80,18 @@ def lib():
         L.orc_alm_optimize.restype = i
         L.orc_alm_optimize.argtypes = [vp, dp, dp, dp, i, dp, dp, dp, i, d, dp, dp]
         L.orc_alm_report.argtypes = [vp, dp]
+        L.orc_alm_set_capture.argtypes = [vp, i, i, i]
+        L.orc_alm_get_iter_log.restype = i
+        L.orc_alm_get_iter_log.argtypes = [vp, ip, i]
+        L.orc_alm_get_capture.restype = i
+        L.orc_alm_get_capture.argtypes = [vp] + [dp] * 11
+        L.orc_alm_lbfgs_resume.restype = i
+        L.orc_alm_lbfgs_resume.argtypes = [vp, i] + [dp] * 8 + [i]
+        L.orc_alm_num_passes.restype = i
+        L.orc_alm_num_passes.argtypes = [vp]
+        L.orc_alm_get_pass.restype = i
+        L.orc_alm_get_pass.argtypes = [vp, i] + [dp] * 9
+        L.orc_alm_pass.argtypes = [vp, i, dp, dp]
         L.orc_alm_get_trace.restype = i
         L.orc_alm_get_trace.argtypes = [vp, dp, i]
         L.orc_mapbuilder_create.restype = vp
@@ -266,6 +278,59 @@ class OracleALM:
         return dict(ret=ret, x=x, alm_iters=int(stats[0]), lbfgs_iters=int(stats[1]), evals=int(stats[2]),
                     last_lbfgs_ret=int(stats[3]), cost=stats[4], wall_ms=stats[5], c_xy=cxy, c_yaw=cyaw,
                     T_xy=txy, T_yaw=tyaw, jerk_cost=jc)
+
+    # ---- teacher-forced test aids ------------------------------------------------------------------------------------
+    def set_capture(self, snap_pass=-1, snap_k=-1, record_passes=True):
+        """ask the next optimize() to capture the L-BFGS state at the top of iteration snap_k of ALM pass snap_pass and to record every pass"""
+        self.L.orc_alm_set_capture(self.h, int(snap_pass), int(snap_k), int(bool(record_passes)))
+
+    def iter_log(self, cap=200000):
+        """(rows, 6) int array {pass, k, ls, bound, end, updated} of every completed L-BFGS iteration of the last optimize()"""
+        buf = np.zeros((cap, 6), dtype=np.int32)
+        n = self.L.orc_alm_get_iter_log(self.h, buf.ctypes.data_as(C.POINTER(C.c_int)), cap)
+        return buf[:min(n, cap)]
+
+    def _state_bufs(self):
+        n, m, past = self.n_vars, int(self.pv[PARAM_ORDER.index("mem_size")]), max(1, int(self.pv[PARAM_ORDER.index("past")]))
+        return dict(x=np.zeros(n), g=np.zeros(n), d=np.zeros(n), pf=np.zeros(past), lm_ys=np.zeros(m), lm_s=np.zeros((m, n)), lm_y=np.zeros((m, n)), scal=np.zeros(5))
+
+    def capture(self):
+        """the captured state (dict) or None; includes lambda / mu / rho in force during that pass"""
+        self.n_vars = 2 * (self.piece_xy - 1) + (self.piece_yaw - 1) + 1
+        b = self._state_bufs()
+        lam, mu, rho = np.zeros(self.S), np.zeros(6 * self.S), np.zeros(1)
+        ok = self.L.orc_alm_get_capture(self.h, *[_dp(b[k]) for k in ("x", "g", "d", "pf", "lm_ys", "lm_s", "lm_y", "scal")], _dp(lam), _dp(mu), _dp(rho))
+        if not ok:
+            return None
+        b.update(step=b["scal"][0], fx=b["scal"][1], k=int(b["scal"][2]), end=int(b["scal"][3]), bound=int(b["scal"][4]), lam=lam, mu=mu, rho=rho[0])
+        return b
+
+    def lbfgs_resume(self, st, budget):
+        """continue from state dict `st` (as returned by capture()) for at most `budget` iterations; returns (code, new state); 999 = still running"""
+        b = {k: np.ascontiguousarray(st[k], dtype=np.float64).copy() for k in ("x", "g", "d", "pf", "lm_ys", "lm_s", "lm_y")}
+        scal = np.array([st["step"], st["fx"], st["k"], st["end"], st["bound"]], dtype=np.float64)
+        ret = self.L.orc_alm_lbfgs_resume(self.h, b["x"].size, *[_dp(b[k]) for k in ("x", "g", "d", "pf", "lm_ys", "lm_s", "lm_y")], _dp(scal), int(budget))
+        b.update(step=scal[0], fx=scal[1], k=int(scal[2]), end=int(scal[3]), bound=int(scal[4]))
+        return ret, b
+
+    def passes(self):
+        out = []
+        n = 2 * (self.piece_xy - 1) + (self.piece_yaw - 1) + 1
+        for i in range(self.L.orc_alm_num_passes(self.h)):
+            r = dict(x_in=np.zeros(n), x_out=np.zeros(n), lam_in=np.zeros(self.S), lam_out=np.zeros(self.S), mu_in=np.zeros(6 * self.S), mu_out=np.zeros(6 * self.S),
+                     hx=np.zeros(self.S), gx=np.zeros(6 * self.S))
+            scal = np.zeros(6)
+            self.L.orc_alm_get_pass(self.h, i, *[_dp(r[k]) for k in ("x_in", "x_out", "lam_in", "lam_out", "mu_in", "mu_out", "hx", "gx")], _dp(scal))
+            r.update(rho_in=scal[0], rho_out=scal[1], cost=scal[2], ret=int(scal[3]), k=int(scal[4]), converged=int(scal[5]))
+            out.append(r)
+        return out
+
+    def alm_pass(self, x):
+        """ONE ALM pass from x with the current duals / scales / rho.  Returns dict(ret, k, accepted, converged, cost, x)"""
+        x = _f64(x).copy()
+        o = np.zeros(5)
+        self.L.orc_alm_pass(self.h, x.size, _dp(x), _dp(o))
+        return dict(ret=int(o[0]), k=int(o[1]), accepted=int(o[2]), converged=int(o[3]), cost=o[4], x=x)
 
     def trace(self, cap=20000):
         """cost after every accepted L-BFGS iteration of the last optimize(); -1 marks the start of an ALM pass"""

@@ -3,7 +3,6 @@
 // stand-in for the workgroup object so that the optimiser's state machine (evaluation, scaling, L-BFGS, ALM) can be
 // checked against the oracle in the CPU-only test tier, before any GPU time is spent.  The reduction order mimics
 // DevWG (per-lane strided partials -> 64-lane xor butterfly -> sequential over the 4 waves).
-#define UPH_COMPACT_DIRECTION 1   // the emulator always carries the experimental compact direction (selected unless UPH_TWOLOOP is set)
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -101,37 +100,33 @@ struct HostWG {
         for (int l = 0; l < 64; l++) tot += part[l];
         *dg_out = tot;
     }
-    // compact L-BFGS direction, plain loops (see DevWG::directionT for the formulas); the Gram entries are recomputed from the rows
-    void direction(double* d, const double* g, const double* /*ynew*/, int n, const double* S, const double* Y, const double*, const double*, double*, double*, double*,
-                   const double* ysTab, double*, double* dg_out, int m, int end, int bound, double gamma) {
-        const int b = bound;
-        std::vector<int> sl(b);
-        for (int k = 0; k < b; k++) sl[k] = ((end - b + k) % m + m) % m;
-        std::vector<double> u(b), v(b), R((size_t)b * b, 0.0), YY((size_t)b * b, 0.0), p1(b), rhs(b), a(b);
-        for (int k = 0; k < b; k++) {
-            double su = 0, sv = 0;
-            for (int t = 0; t < n; t++) { su += S[(size_t)sl[k] * n + t] * g[t]; sv += Y[(size_t)sl[k] * n + t] * g[t]; }
-            u[k] = su; v[k] = sv;
+    // MINCO knot sweeps (DevWG::thomas): the same per-knot arithmetic, plain serial loops
+    template <bool ADJ>
+    static void thomasChain(const double* tab, double* buf, int len, int ks, int cs) {
+        double y0 = 0.0, y1 = 0.0;
+        for (int j = 1; j <= len; j++) {
+            double P[4], M1[4], Q[4], M2[4];
+            thomasFactors<ADJ>(tab, j, P, M1, Q, M2);
+            double* p = buf + (size_t)(j - 1) * ks;
+            double P0, P1;
+            mv2(P, p[0], p[cs], P0, P1);
+            submv2(P0, P1, M1, y0, y1, y0, y1);
+            p[0] = y0; p[cs] = y1;
         }
-        for (int i = 0; i < b; i++)
-            for (int j = 0; j < b; j++) {
-                double sy = 0, yy = 0;
-                for (int t = 0; t < n; t++) { sy += S[(size_t)sl[i] * n + t] * Y[(size_t)sl[j] * n + t]; yy += Y[(size_t)sl[i] * n + t] * Y[(size_t)sl[j] * n + t]; }
-                if (i < j) R[(size_t)i * b + j] = sy;
-                YY[(size_t)i * b + j] = yy;
-            }
-        std::vector<double> w(u);
-        for (int j = b - 1; j >= 0; j--) { p1[j] = w[j] * ysTab[2 * sl[j] + 1]; for (int i = 0; i < j; i++) w[i] = std::fma(-R[(size_t)i * b + j], p1[j], w[i]); }
-        for (int i = 0; i < b; i++) { double yyp = 0; for (int j = b - 1; j >= 0; j--) yyp = std::fma(YY[(size_t)i * b + j], p1[j], yyp); rhs[i] = ysTab[2 * sl[i]] * p1[i] + gamma * (yyp - v[i]); }
-        for (int i = 0; i < b; i++) { a[i] = rhs[i] * ysTab[2 * sl[i] + 1]; for (int j = i + 1; j < b; j++) rhs[j] = std::fma(-R[(size_t)i * b + j], a[i], rhs[j]); }
-        double tot = 0.0;
-        for (int t = 0; t < n; t++) {
-            double acc = gamma * g[t];
-            for (int k = 0; k < b; k++) acc += S[(size_t)sl[k] * n + t] * a[k] + Y[(size_t)sl[k] * n + t] * (-gamma * p1[k]);
-            d[t] = -acc;
-            tot += g[t] * d[t];
+        double z0 = 0.0, z1 = 0.0;
+        for (int j = len; j >= 1; j--) {
+            double P[4], M1[4], Q[4], M2[4];
+            thomasFactors<ADJ>(tab, j, P, M1, Q, M2);
+            double* p = buf + (size_t)(j - 1) * ks;
+            double q0, q1;
+            mv2(Q, p[0], p[cs], q0, q1);
+            submv2(q0, q1, M2, z0, z1, z0, z1);
+            p[0] = z0; p[cs] = z1;
         }
-        *dg_out = tot;
+    }
+    void thomas(const double* tab, bool adj, double* bw, int lenW, double* bx, int lenX) {
+        if (adj) { thomasChain<true>(tab, bw, lenW, 2, 1); thomasChain<true>(tab, bx, lenX, 4, 2); thomasChain<true>(tab, bx + 1, lenX, 4, 2); }
+        else { thomasChain<false>(tab, bw, lenW, 2, 1); thomasChain<false>(tab, bx, lenX, 4, 2); thomasChain<false>(tab, bx + 1, lenX, 4, 2); }
     }
     template <class F>
     double maxv(int n, F f) {
@@ -211,7 +206,7 @@ void emu_run(void* h, int mode, int n_inner_xy, int n_inner_yaw, const double* i
     std::memset(&st, 0, sizeof(st));
     st.rho = scal[0]; st.scale_fx = scal[1];
     std::vector<double> dual(7 * S), res(7 * S, 0.0), scl(7 * S), xg(x_io, x_io + n), gout(n, 0.0), cxy(12 * td.Nxy), cyaw(6 * td.Nyaw);
-    std::vector<double> lms((size_t)e->P.mem_size * n), lmy((size_t)e->P.mem_size * n), rep(7, 0.0), lmys(2 * (size_t)e->P.mem_size, 0.0), xpgp(2 * n, 0.0);
+    std::vector<double> lms((size_t)e->P.mem_size * n), lmy((size_t)e->P.mem_size * n), rep(7, 0.0), lmys(2 * (size_t)e->P.mem_size, 0.0);
     g_trace.assign(20000, 0.0);
     for (int s = 0; s < S; s++) {
         dual[s] = lambda_io[s];
@@ -221,7 +216,7 @@ void emu_run(void* h, int mode, int n_inner_xy, int n_inner_yaw, const double* i
     BatchDev bd;
     std::memset(&bd, 0, sizeof(bd));
     bd.B = 1; bd.desc = &td; bd.state = &st; bd.ops = ops; bd.x = xg.data(); std::vector<double> x0copy(xg); bd.x0 = x0copy.data(); bd.gout = gout.data(); bd.dual = dual.data(); bd.res = res.data();
-    bd.scl = scl.data(); bd.cxy = cxy.data(); bd.cyaw = cyaw.data(); bd.lm_s = lms.data(); bd.lm_y = lmy.data(); bd.lm_ys = lmys.data(); bd.xpgp = xpgp.data(); bd.compact = getenv("UPH_TWOLOOP") ? 0 : 1; std::vector<double> lmst((size_t)e->P.mem_size * n), lmyt((size_t)e->P.mem_size * n), gram(3); bd.lm_st = lmst.data(); bd.lm_yt = lmyt.data(); bd.lm_sy = gram.data(); bd.lm_ysT = gram.data(); bd.lm_yy = gram.data(); bd.report = rep.data(); bd.trace = g_trace.data(); bd.trace_cap = (int)g_trace.size();
+    bd.scl = scl.data(); bd.cxy = cxy.data(); bd.cyaw = cyaw.data(); bd.lm_s = lms.data(); bd.lm_y = lmy.data(); bd.lm_ys = lmys.data(); std::vector<double> thomasTab; buildThomasTable(thomasTab); bd.thomas = thomasTab.data(); bd.report = rep.data(); bd.trace = g_trace.data(); bd.trace_cap = (int)g_trace.size();
     std::vector<double> lds(Solver<HostWG>::ldsDoubles(td.Nxy, td.Nyaw, n, g_lanes, e->P.mem_size, e->P.int_K) + 64);
     HostWG wg;
     Solver<HostWG> sol(wg, e->grid, e->P, bd, 0, lds.data());

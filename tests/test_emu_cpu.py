@@ -44,14 +44,8 @@ def test_emu_terrain_eval_scaling(emu, oracle, oracle_grid, hill_problem, small_
         assert rel(s2["scale_cx"], r2["scale_cx"]) < 1e-10
 
 
-@pytest.mark.parametrize("direction", ["compact", "twoloop"])
-def test_emu_full_solve_tracks_oracle(emu, oracle, oracle_grid, small_problems, direction, monkeypatch):
-    """the workgroup program's state machine against the oracle, with both forms of the L-BFGS direction: the two-loop recursion
-    (product default) and the compact representation (experimental build option -DUPH_COMPACT_DIRECTION=1, always in the emulator)"""
-    if direction == "twoloop":
-        monkeypatch.setenv("UPH_TWOLOOP", "1")
-    else:
-        monkeypatch.delenv("UPH_TWOLOOP", raising=False)
+def test_emu_full_solve_tracks_oracle(emu, oracle, oracle_grid, small_problems):
+    """the workgroup program's state machine (ALM / L-BFGS / line search / two-loop) against the oracle"""
     E.lib().emu_set_lanes(256)
     for prob in small_problems:
         a = oracle.OracleALM(oracle_grid)

@@ -119,23 +119,3 @@ def test_trajectory_leaving_the_map(devmap, oracle, oracle_grid):
     x0 = a.setup(p)
     fo, go, _ = a.eval(x0)
     assert abs(f[0] - fo) / abs(fo) < 1e-9 and rel(go, g[0]) < 1e-9
-
-
-def test_direction_knob_in_the_default_build(devmap, small_problems):
-    """the compact L-BFGS direction is a build option (COMPACT=1): the default library refuses to select it and stays usable"""
-    import uneven_planner_amd as U
-    opt = U.ALMTrajOpt(devmap)
-    opt.set_direction(0)                                         # the two-loop recursion is always there
-    try:
-        opt.set_direction(1)
-        compact_built = True
-    except U._lib.UnevenHipError as e:
-        compact_built = False
-        assert "COMPACT" in str(e).upper()
-    out = opt.optimize_batch(small_problems[:1])[0]
-    assert out["ret"] in (0, 2)
-    if compact_built:                                            # a COMPACT=1 build: both forms reach the same optimum at the floor level
-        opt.set_direction(0)
-        opt.set_rho(1.0)
-        ref = opt.optimize_batch(small_problems[:1])[0]
-        assert abs(out["cost"] - ref["cost"]) / abs(ref["cost"]) < 5e-2

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunevenhip.so")
+# UNEVENHIP_LIB selects another build of the same library (tools/build_variants.sh: A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("UNEVENHIP_LIB") or os.path.join(_HERE, "libunevenhip.so")
 
 
 class MapParams(C.Structure):
@@ -65,7 +66,6 @@ SYMBOLS = {
     "uph_ctx_destroy": (None, [_VP]),
     "uph_ctx_set_lanes": (C.c_int, [_VP, _I32]),
     "uph_ctx_set_wps": (C.c_int, [_VP, _I32]),
-    "uph_ctx_set_direction": (C.c_int, [_VP, _I32]),
     "uph_ctx_set_rho": (C.c_int, [_VP, C.c_double]),
     "uph_ctx_get_rho": (C.c_int, [_VP, DP]),
     "uph_ctx_set_trace": (C.c_int, [_VP, _I32]),

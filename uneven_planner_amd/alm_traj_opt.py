@@ -87,12 +87,8 @@ class ALMTrajOpt:
         self.h = h
 
     def set_lanes(self, lanes):
-        """64 = one wave per trajectory (throughput), 256 = four waves (latency), 0 = automatic"""
+        """64 / 128 / 256 lanes (one / two / four waves) per trajectory, 0 = automatic"""
         _lib.check(self.L.uph_ctx_set_lanes(self.h, int(lanes)), "uph_ctx_set_lanes")
-
-    def set_direction(self, compact):
-        """1 = compact L-BFGS direction (default), 0 = two-loop recursion in the reference's order"""
-        _lib.check(self.L.uph_ctx_set_direction(self.h, int(compact)), "uph_ctx_set_direction")
 
     def set_wps(self, wps):
         _lib.check(self.L.uph_ctx_set_wps(self.h, int(wps)), "uph_ctx_set_wps")
@@ -144,8 +140,8 @@ class ALMTrajOpt:
         return dict(kernel_ms=ms.value, prepare_ms=pm.value, evals=v[0].value, sample_evals=v[1].value, lbfgs_iters=v[2].value, hist_bytes=v[3].value)
 
     def cycles(self):
-        """(B,8) shader-clock cycles per phase of the last solve (generate, samples, scatter, adjoint, two-loop, scaling, total)"""
-        out = np.zeros((self._B, 8), dtype=np.int64)
+        """(B,16) shader-clock cycles per phase of the last solve (generate, samples, scatter, adjoint, two-loop, scaling, total, ...)"""
+        out = np.zeros((self._B, 16), dtype=np.int64)
         _lib.check(self.L.uph_batch_cycles(self.h, out.ctypes.data_as(C.POINTER(C.c_longlong))), "uph_batch_cycles")
         return out
 

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <vector>
 
+#include "uph_common.hpp"
+
 namespace uph {
 
 inline void buildMincoOp(int N, std::vector<double>& Wt /* [col][row] */, std::vector<double>& Wr /* [row][col] */) {
@@ -81,6 +83,43 @@ inline void buildMincoOp(int N, std::vector<double>& Wt /* [col][row] */, std::v
                 Wt[(size_t)c * nr + r] = v;
             }
         }
+}
+
+}  // namespace uph
+
+namespace uph {
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Block-tridiagonal form of the same system (used by generate() / adjoint(); solver_program.hpp, uph_common.hpp thomasFactors).
+// With z_j = (v_j, a_j) in normalised time, jerk and snap continuity at interior knot j read (rows divided by 3 and 24)
+//     A z_{j-1} + B z_j + C z_{j+1} = r_j,      r_j = ( 20 (dl+ - dl-), -15 (dl+ + dl-) ),   dl+ = p_{j+1} - p_j,  dl- = p_j - p_{j-1},
+//     A = [-8 -1; -7 -1],  B = [0 6; -16 0],  C = [8 -1; -7 1]
+// (from the quintic Hermite form: end jerk 60 dl - 24 v0 - 36 v1 - 3 a0 + 9 a1, start jerk 60 dl - 36 v0 - 24 v1 - 9 a0 + 3 a1,
+//  end snap 360 dl - 168 v0 - 192 v1 - 24 a0 + 36 a1, start snap -360 dl + 192 v0 + 168 v1 + 36 a0 - 24 a1).
+// Block LU from the left: D_1 = B, L_j = A D_{j-1}^-1, D_j = B - L_j C.  The factors do not depend on N (the left end is always
+// "z_0 known"), so ONE table serves every trajectory; ||L_j|| -> spectral radius 0.43, cond(D_j) ~ 3: no pivoting needed.
+// Table entry j = knot index, 8 doubles: L_j (row-major 2x2; zero for j = 1) | D_j^-1.  The factors converge geometrically (rate
+// 0.43^2 per knot) and are bit-constant in fp64 from j = 26 on, so the table stops there: knot j uses entry min(j, THOMAS_J).
+// 27 x 8 doubles = 1.7 KB -- small enough to sit in LDS for the whole solve (uph::thomasFactors derives the products with C).
+inline void buildThomasTable(std::vector<double>& tab) {
+    typedef long double R;
+    struct M2 { R a, b, c, d; };
+    auto mul = [](const M2& x, const M2& y) { return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; };
+    auto inv = [](const M2& x) { const R det = x.a * x.d - x.b * x.c; return M2{x.d / det, -x.b / det, -x.c / det, x.a / det}; };
+    const M2 A{-8, -1, -7, -1}, B{0, 6, -16, 0}, C{8, -1, -7, 1}, Z{0, 0, 0, 0};
+    tab.assign((size_t)(THOMAS_J + 1) * THOMAS_STRIDE, 0.0);
+    M2 D = B, Di = inv(D), L = Z;
+    for (int j = 1; j <= THOMAS_J; j++) {
+        if (j > 1) {
+            L = mul(A, Di);
+            const M2 LC = mul(L, C);
+            D = M2{B.a - LC.a, B.b - LC.b, B.c - LC.c, B.d - LC.d};
+            Di = inv(D);
+        }
+        double* t = &tab[(size_t)j * THOMAS_STRIDE];
+        t[0] = (double)L.a; t[1] = (double)L.b; t[2] = (double)L.c; t[3] = (double)L.d;
+        t[4] = (double)Di.a; t[5] = (double)Di.b; t[6] = (double)Di.c; t[7] = (double)Di.d;
+    }
 }
 
 }  // namespace uph

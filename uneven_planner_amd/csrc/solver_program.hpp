@@ -12,15 +12,17 @@
 //   Solver::jerk*        <- getTrajJerkCost / calJerkGradCT        se2traj.hpp:697-747
 //   Solver::report       <- getMaxVxAxAyCurAttSig + getNonHolError alm_traj_opt.h:170-229, se2traj.hpp:551-561
 //
-// MINCO as a knot operator.  The reference gives every piece the same duration (calTfromTau, alm_traj_opt.h:257-261).
+// MINCO as a knot system.  The reference gives every piece the same duration (calTfromTau, alm_traj_opt.h:257-261).
 // In normalised time s = t/T (c~_k = c_k T^k) the banded system of se2traj.hpp:612-674 no longer depends on T:
-// A(1) c~ = b~ with b~ = [P0, T V0, T^2 A0, ..q_i.., Pf, T Vf, T^2 Af].  A quintic piece is fixed by (p, v, a) at its two
-// ends, so only the interior knots' (v_j, a_j) are solved for: W = the matching 2(N-1) rows of A(1)^-1 restricted to its
-// N+5 live columns (MincoOp, built once per N on the host).  generate() = W b~ (one mat-vec) + the constant quintic Hermite
-// map per piece; calGradCTtoQT() = the transposed Hermite map + W^T -- fully parallel, no 6N-step serial elimination on the
-// GPU.  The time gradient follows from c_k = c~_k T^-k:
+// A(1) c~ = b~ with b~ = [P0, T V0, T^2 A0, ..q_i.., Pf, T Vf, T^2 Af].  A quintic piece is fixed by (p, v, a) at its two ends,
+// so only the interior knots' z_j = (v_j, a_j) are solved for -- jerk and snap continuity at every interior knot, a block-
+// tridiagonal system with constant 2x2 blocks whose block-LU factors do not depend on N and sit in LDS (minco_op_host.hpp).
+// generate() = right-hand sides + one fused forward/backward sweep (wg.thomas) + the constant quintic Hermite map per piece;
+// calGradCTtoQT() = the transposed Hermite map + the transposed sweeps.  The time gradient follows from c_k = c~_k T^-k:
 //   sum_i dW/dT_i = sum_i dK/dT_i - sum_{i,k} (k c_ik / T) dK/dc_ik + <gamma, db~/dT>,  gamma = M^T (dK/dc . T^-k),
-// M = (Hermite expansion) o W; identical to the reference's dK/dT_i - <B_i, lambda> in exact arithmetic.
+// M = (Hermite expansion) o (knot solve); identical to the reference's dK/dT_i - <B_i, lambda> in exact arithmetic.
+// initScaling needs single rows of the inverse instead (one sparse adjoint per constraint): it gathers them from the dense knot
+// operator W = the 2(N-1) x (N+5) restriction of A(1)^-1 (MincoOp, built once per N on the host).
 //
 // Wave-uniform values (reduction results, T, rho, scales, per-evaluation constants, line-search scalars) pass through
 // wg.bcast(): on the device that is v_readfirstlane, which parks them in scalar registers -- see DevWG::uni in unevenhip.hip
@@ -38,9 +40,6 @@ namespace uph {
 #ifndef UPH_SC_YB
 #define UPH_SC_YB 10
 #endif
-#ifndef UPH_MV_BW
-#define UPH_MV_BW 12
-#endif
 
 template <class WG>
 struct Solver {
@@ -52,39 +51,33 @@ struct Solver {
     int Nxy, Nyaw, n, S, K, mem, CH, CHP, recd;
     // workgroup-shared arrays (LDS)
     int* rtag;
-    double *x, *xp, *g, *gp, *d, *bxy, *byaw, *cxy, *cyaw, *Gxy, *Gyaw, *gamxy, *gamyaw, *bt, *rec, *lm_ys, *pf, *mvp, *hd;
+    double *x, *xp, *g, *gp, *d, *cxy, *cyaw, *Gxy, *Gyaw, *gamxy, *gamyaw, *bt, *rec, *wtab, *ttab, *lm_ys, *pf, *hd;
     // HBM
     double *dual, *res, *scl, *lm_s, *lm_y;
-#if UPH_COMPACT_DIRECTION
-    double *lm_st, *lm_yt, *gm_sy, *gm_ys, *gm_yy;       // compact L-BFGS direction: transposed history, Gram matrices (HBM)
-#endif
-    const double *Wt_xy, *Wr_xy, *Wt_yaw, *Wr_yaw;      // knot operators (v_j, a_j of the interior knots) in both layouts
+    const double *Wr_xy, *Wr_yaw;                       // dense knot operators [row][col] (initScaling's row gathers)
     // uniform scalars (identical in every lane)
     double rho, scale_fx, Txy, Tyaw, last_jerk;
     long long hist_reads;
-    long long cyc[8];
+    long long cyc[16];
     long long t_last_eval_end;
-    long long* sub_t = nullptr;      // microbenchmark hook: accumulates sub-step ticks of generate() [0..1] and adjoint() [2..4]
+    long long* sub_t = nullptr;      // microbenchmark hook: sub-step ticks of generate() [0 rhs, 1 knot solve], expand() [2], adjoint() [4 transposed Hermite, 5 knot solve, 6 gamma]
     int evals, bidx, trace_n;
     float inv_k1;                           // 1 / (K + 1) for divSmall
     // per-evaluation wave-uniform constants of the sample loop, formed once and parked in scalar registers
     double ec_irho, ec_step, ec_invK, ec_iTyaw, ec_omega, ec_omega_h;
 
-    // S is no longer part of the footprint: samples are processed in chunks of CH = workgroup size (records of one chunk only)
-    static constexpr int REC_FIELDS = 18;   // per-sample record: 12 xy-block + 6 yaw-block gradient contributions (+ an int32 yaw-piece tag)
-    static constexpr int MV_CHUNKS = 4;     // the mat-vecs split their summation index into this many chunks (partials in LDS)
+    // S is not part of the footprint: samples are processed in chunks of CH = workgroup size (records of one chunk only)
+    static constexpr int REC_FIELDS = 12;   // per-sample record: grad_p, grad_v, grad_a (2 each) + its 6 yaw-block contributions (+ an int32 yaw-piece tag)
     static UPH_HD size_t ldsDoubles(int Nxy, int Nyaw, int n, int CH, int mem, int K) {
-        size_t recd = (size_t)REC_FIELDS * (CH + 1) + (CH + 1) / 2;       // 18 double fields (stride CH + 1: bank spread) + the int32 yaw-piece tags
-        const size_t nvec = 2 * (Nxy + 5) + (Nyaw + 5);                   // the record buffer doubles as mat-vec scratch (generate / adjoint)
-        const size_t mvd = 2 * (size_t)CH + 3 * nvec, knd = 4 * (size_t)(Nxy + 1) + 2 * (Nyaw + 1);
-        recd = recd < mvd ? mvd : recd;
+        size_t recd = (size_t)REC_FIELDS * (CH + 1) + (CH + 1) / 2;       // double fields (stride CH + 1: bank spread) + the int32 yaw-piece tags
+        const size_t nvec = 2 * (Nxy + 5) + (Nyaw + 5);
+        // the record buffer is idle outside the sample loop: knot states of generate(), knot gradients + direct parts of adjoint()
+        const size_t knd = 4 * (size_t)(Nxy + 1) + 2 * (Nyaw + 1), adj = 4 * (size_t)(Nxy - 1) + 2 * (Nyaw - 1) + nvec;
         recd = recd < knd ? knd : recd;
-        recd = recd < (size_t)mem ? (size_t)mem : recd;                  // ... and parks the two-loop's alphas
-#if UPH_COMPACT_DIRECTION
-        { const size_t mb = mem < 256 ? ((mem + 63) / 64) * 64 : 256, dird = (size_t)n + 2 + (CH / 64) * 4 * mb; recd = recd < dird ? dird : recd; }   // ... or y_new + the direction's partial sums
-#endif
-        const size_t bd_ = (size_t)(Nxy + 5) * 2 + (Nyaw + 5), td_ = (size_t)Nxy + K + 2;      // beta buffers, also home of the sample-time tables
-        return (size_t)3 * n + (bd_ < td_ ? td_ : bd_) + 2 * (12 * Nxy + 6 * Nyaw) + recd + MAX_PAST + 8 + 18;
+        recd = recd < adj ? adj : recd;
+        recd = recd < (size_t)mem ? (size_t)mem : recd;                  // ... and the two-loop's alphas
+        const size_t td_ = (size_t)Nxy + K + 2;                          // sample-time tables; gamma lives in the same words after adjoint()
+        return (size_t)5 * n + (nvec < td_ ? td_ : nvec) + 2 * (12 * Nxy + 6 * Nyaw) + recd + (size_t)18 * (K + 1) + THOMAS_DOUBLES + MAX_PAST + 8 + 18;
     }
 
     UPH_HD Solver(WG& w, const GridDev& gr, const OptParams& p, const BatchDev& b, int bi, double* lds)
@@ -93,38 +86,41 @@ struct Solver {
         Nxy = td.Nxy; Nyaw = td.Nyaw; n = td.n; S = td.S; K = P.int_K; mem = P.mem_size;
         inv_k1 = 1.0f / (float)(K + 1);
         CH = wg.size(); CHP = CH + 1; recd = REC_FIELDS * CHP + (CH + 1) / 2;      // (ldsDoubles may have reserved more; only the size matters here)
-        // field stride CH + 1 doubles: with stride CH (1 KB) the twelve field rows of a piece start in the same LDS bank and the
-        // scatter's per-(piece, field) lanes conflict 12 ways
+        // field stride CH + 1 doubles: with stride CH (1 KB) the field rows of a piece start in the same LDS bank and the
+        // scatter's per-(piece, field) lanes conflict
         double* q = lds;
         x = q; q += n; g = q; q += n; d = q; q += n;
-        xp = bd.xpgp + 2 * td.off_x; gp = xp + n;            // previous iterate / gradient live in HBM (touched twice per iteration)
-        bxy = q; q += (Nxy + 5) * 2; byaw = q; q += Nyaw + 5;
-        if (Nxy + K + 2 > (Nxy + 5) * 2 + (Nyaw + 5)) q += (Nxy + K + 2) - ((Nxy + 5) * 2 + (Nyaw + 5));   // room for the time tables (large K)
-        gamxy = bxy; gamyaw = byaw;                          // gamma (adjoint output) reuses the beta buffers (dead after generate)
-        bt = bxy;                                            // ... and so do the sample-time tables, between initG and adjoint (fillTimes)
+        xp = q; q += n; gp = q; q += n;                      // iterate / gradient the line search starts from
+        const int nvec = 2 * (Nxy + 5) + (Nyaw + 5);
+        bt = q;                                              // sample-time tables (fillTimes), alive from expand() to adjoint()
+        gamxy = q; gamyaw = q + 2 * (Nxy + 5);               // gamma (adjoint output) takes the same words afterwards
+        q += nvec < Nxy + K + 2 ? Nxy + K + 2 : nvec;
         cxy = q; q += 12 * Nxy; cyaw = q; q += 6 * Nyaw;
         Gxy = q; q += 12 * Nxy; Gyaw = q; q += 6 * Nyaw;
-        rec = q; q += recd;
+        rec = q;
+        {
+            size_t rd = (size_t)recd;
+            const size_t knd = 4 * (size_t)(Nxy + 1) + 2 * (Nyaw + 1), adj = 4 * (size_t)(Nxy - 1) + 2 * (Nyaw - 1) + nvec;
+            rd = rd < knd ? knd : rd; rd = rd < adj ? adj : rd; rd = rd < (size_t)mem ? (size_t)mem : rd;
+            q += rd;
+        }
         rtag = (int*)(rec + (size_t)REC_FIELDS * CHP);
-        lm_ys = bd.lm_ys + (size_t)bidx * 2 * mem;   // pair curvatures and their reciprocals, in HBM
+        wtab = q; q += 18 * (K + 1);                         // basis weights of the K + 1 in-piece sample times: [j][k][beta0, beta1, beta2]
+        ttab = q; q += THOMAS_DOUBLES;                       // block-LU factors of the knot system
+        lm_ys = bd.lm_ys + (size_t)bidx * 2 * mem;           // pair curvatures and their reciprocals, in HBM
         pf = q; q += MAX_PAST + 8;
         hd = q; q += 18;                                     // head / tail states {P,V,A}: init_xy[6], end_xy[6], init_yaw[3], end_yaw[3]
-        mvp = rec;        // the adjoint's partial sums reuse the record buffer (records are consumed by scatterChunk before adjoint runs)
         dual = bd.dual + 7 * td.off_s; res = bd.res + 7 * td.off_s; scl = bd.scl + 7 * td.off_s;
         lm_s = bd.lm_s + td.off_hist; lm_y = bd.lm_y + td.off_hist;
-#if UPH_COMPACT_DIRECTION
-        if (bd.compact) {
-            lm_st = bd.lm_st + td.off_hist; lm_yt = bd.lm_yt + td.off_hist;
-            gm_sy = bd.lm_sy + (size_t)bidx * mem * mem; gm_ys = bd.lm_ysT + (size_t)bidx * mem * mem; gm_yy = bd.lm_yy + (size_t)bidx * mem * mem;
-        } else { lm_st = lm_yt = gm_sy = gm_ys = gm_yy = nullptr; }
-#endif
-        Wt_xy = bd.ops[td.op_xy].Wt; Wr_xy = bd.ops[td.op_xy].Wr;
-        Wt_yaw = bd.ops[td.op_yaw].Wt; Wr_yaw = bd.ops[td.op_yaw].Wr;
+        Wr_xy = bd.ops[td.op_xy].Wr; Wr_yaw = bd.ops[td.op_yaw].Wr;
         rho = 0; scale_fx = 1.0; Txy = Tyaw = 0; last_jerk = 0; hist_reads = 0; evals = 0; trace_n = 0;
-        for (int q = 0; q < 8; q++) cyc[q] = 0;
+        for (int q = 0; q < 16; q++) cyc[q] = 0;
         t_last_eval_end = 0;
-        // the end states are read by every generate() / adjoint(): one copy from the descriptor (HBM) into LDS per launch
-        wg.pfor(18, [&](int t) { hd[t] = t < 6 ? td.init_xy[t] : (t < 12 ? td.end_xy[t - 6] : (t < 15 ? td.init_yaw[t - 12] : td.end_yaw[t - 15])); });
+        // read by every generate() / adjoint(): one copy per launch of the end states (descriptor) and the factor table (HBM) into LDS
+        wg.pfor(18 + THOMAS_DOUBLES, [&](int t) {
+            if (t < 18) hd[t] = t < 6 ? td.init_xy[t] : (t < 12 ? td.end_xy[t - 6] : (t < 15 ? td.init_yaw[t - 12] : td.end_yaw[t - 15]));
+            else ttab[t - 18] = bd.thomas[t - 18];
+        });
     }
 
     // optional diagnostic: cost after every accepted L-BFGS iteration (-1 marks the start of an ALM pass); off when bd.trace == nullptr
@@ -144,8 +140,13 @@ struct Solver {
         else if (r >= b) q++;
         return q;
     }
-    // column of beta that holds the position of knot j (head P | way-points | tail P)
+    // column of beta = [P0, T V0, T^2 A0 | way-points | PN, T VN, T^2 AN] that holds the position of knot j
     static UPH_HD int knotCol(int j, int N) { return j == 0 ? 0 : (j == N ? N + 2 : j + 2); }
+    // position of knot j (0..N) of dimension dd (0, 1: xy; 2: yaw): an end state or a way-point of x
+    UPH_HD double knotPos(const double* xin, int j, int dd) const {
+        if (dd < 2) return j == 0 ? hd[dd] : (j == Nxy ? hd[6 + dd] : xin[1 + 2 * (j - 1) + dd]);
+        return j == 0 ? hd[12] : (j == Nyaw ? hd[15] : xin[1 + 2 * (Nxy - 1) + (j - 1)]);
+    }
 
     // ------------------------------------------------------------------ small vector helpers
     UPH_HD double dot(const double* a, const double* b, int m) {
@@ -157,137 +158,90 @@ struct Solver {
         return wg.maxv(m, [&](int i) { return fabs(a[i]); });
     }
 
-    // strided dot product  sum_i p[i*stride] * v[i*vs]  (and with v[i*vs+1] when TWO) for the mat-vecs.  Full batches run
-    // without any clamping or per-element address arithmetic (the offsets u*stride are loop invariants, the loads of a
-    // batch are independent); only the last partial batch clamps its indices and masks its products.
-    template <bool TWO>
-    UPH_HD void stridedDot(const double* __restrict__ p, int stride, int count, const double* v, int vs, double& o0, double& o1) const {
-        const auto pg = UPH_AS_GLOBAL(p);
-        static_assert(UPH_MV_BW % 2 == 0, "the strided dot pairs its operands");
-        constexpr int BW = UPH_MV_BW;      // batch width: 16 was measured slower overall (more live registers -> more spills in the capped build)
-        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-        int i = 0;
-        for (; i + BW <= count; i += BW) {
-            const auto pb = pg + (size_t)i * stride;
-            const double* vb = v + i * vs;
-            double mv[BW];
-#pragma unroll
-            for (int u = 0; u < BW; u++) mv[u] = pb[u * stride];
-#pragma unroll
-            for (int u = 0; u < BW; u += 2) {
-                a0 += mv[u] * vb[u * vs];
-                b0 += mv[u + 1] * vb[(u + 1) * vs];
-                if (TWO) { a1 += mv[u] * vb[u * vs + 1]; b1 += mv[u + 1] * vb[(u + 1) * vs + 1]; }
-            }
-        }
-        if (i < count) {
-            const int rem = count - i;
-            const auto pb = pg + (size_t)i * stride;
-            const double* vb = v + i * vs;
-            double mv[BW];
-#pragma unroll
-            for (int u = 0; u < BW; u++) mv[u] = pb[(u < rem ? u : rem - 1) * stride];
-#pragma unroll
-            for (int u = 0; u < BW; u++) {
-                const int uu = u < rem ? u : rem - 1;
-                const double w = u < rem ? mv[u] : 0.0;
-                a0 += w * vb[uu * vs];
-                if (TWO) a1 += w * vb[uu * vs + 1];
-            }
-        }
-        o0 = a0 + b0;
-        o1 = a1 + b1;
-    }
-
-    // ------------------------------------------------------------------ MINCO generate (se2traj.hpp:595-680 as a mat-vec)
+    // ------------------------------------------------------------------ MINCO generate (se2traj.hpp:595-680), part 1: knot states
+    // (v_j, a_j) of the interior knots from the block-tridiagonal jerk / snap continuity system (minco_op_host.hpp): right-hand
+    // sides r_j = (20 (dl+ - dl-), -15 (dl+ + dl-)) in parallel -- the known end states z_0, z_N moved to the right (- A z_0 at
+    // knot 1, - C z_N at knot N-1) --, then ONE fused forward / backward sweep with the 2x2 block factors (wg.thomas).  The knot
+    // states [(N+1)][v,a][dim] sit in the record buffer, which is idle until the first sample chunk.
     UPH_HD void generate(const double* xin) {
         const long long tsub_start = wg.clock();
-        const double tau = xin[0];
-        const double Ttot = expC2(tau);
+        const double Ttot = expC2(xin[0]);
         Txy = wg.bcast(Ttot / (double)Nxy);       // calTfromTau, alm_traj_opt.h:257-261 (wave-uniform: kept in scalar registers)
         Tyaw = wg.bcast(Ttot / (double)Nyaw);
         ec_iTyaw = wg.bcast(1.0 / Tyaw);
         const double Tx = Txy, Ty = Tyaw;
-        const int nbx = Nxy + 5, nby = Nyaw + 5;
-        wg.pfor(nbx * 2 + nby, [&](int t) {
-            if (t < nbx * 2) {
-                int col = t >> 1, dd = t & 1;
-                double v;
-                if (col == 0) v = hd[0 + (0 + dd)];
-                else if (col == 1) v = Tx * hd[0 + (2 + dd)];
-                else if (col == 2) v = Tx * Tx * hd[0 + (4 + dd)];
-                else if (col == Nxy + 2) v = hd[6 + (0 + dd)];
-                else if (col == Nxy + 3) v = Tx * hd[6 + (2 + dd)];
-                else if (col == Nxy + 4) v = Tx * Tx * hd[6 + (4 + dd)];
-                else v = xin[1 + 2 * (col - 3) + dd];
-                bxy[t] = v;
-            } else {
-                int col = t - nbx * 2;
-                double v;
-                if (col == 0) v = hd[12];
-                else if (col == 1) v = Ty * hd[13];
-                else if (col == 2) v = Ty * Ty * hd[14];
-                else if (col == Nyaw + 2) v = hd[15];
-                else if (col == Nyaw + 3) v = Ty * hd[16];
-                else if (col == Nyaw + 4) v = Ty * Ty * hd[17];
-                else v = xin[1 + 2 * (Nxy - 1) + (col - 3)];
-                byaw[col] = v;
+        double* zxy = rec;
+        double* zyaw = rec + 4 * (Nxy + 1);
+        wg.pfor(2 * (Nxy + 1) + (Nyaw + 1), [&](int t) {
+            const bool isxy = t < 2 * (Nxy + 1);
+            const int j = isxy ? (t >> 1) : t - 2 * (Nxy + 1), dd = isxy ? (t & 1) : 2, N = isxy ? Nxy : Nyaw, os = isxy ? 2 : 1;
+            const double T1 = isxy ? Tx : Ty;
+            const double* h0 = isxy ? hd + (dd & 1) : hd + 12;       // {P, V, A} of the head at stride os; tail 6 (xy) / 3 (yaw) doubles further
+            const double* h1 = isxy ? hd + 6 + (dd & 1) : hd + 15;
+            double* z = isxy ? zxy + 4 * j + (dd & 1) : zyaw + 2 * j;      // component stride os
+            if (j == 0) { z[0] = T1 * h0[os]; z[os] = T1 * T1 * h0[2 * os]; }
+            else if (j == N) { z[0] = T1 * h1[os]; z[os] = T1 * T1 * h1[2 * os]; }
+            else {
+                const double pm = knotPos(xin, j - 1, dd), p0 = knotPos(xin, j, dd), pp = knotPos(xin, j + 1, dd);
+                const double dp = pp - p0, dm = p0 - pm;
+                double r0 = 20.0 * (dp - dm), r1 = -15.0 * (dp + dm);
+                if (j == 1) { const double v0 = T1 * h0[os], a0 = T1 * T1 * h0[2 * os]; r0 += 8.0 * v0 + a0; r1 += 7.0 * v0 + a0; }
+                if (j == N - 1) { const double vN = T1 * h1[os], aN = T1 * T1 * h1[2 * os]; r0 += -8.0 * vN + aN; r1 += 7.0 * vN - aN; }
+                z[0] = r0; z[os] = r1;
             }
         });
-        const double itx = 1.0 / Tx, ity = 1.0 / Ty;
-        const long long tsub0 = wg.clock();
-        // (v_j, a_j) of the interior knots = W beta, one lane per operator row (adjacent lanes = adjacent rows: coalesced), in
-        // unconditional batches of operator loads; the end knots copy their (V, A) from beta.  Knot states sit in the record
-        // buffer, which is idle until the first sample chunk.
-        const int kx = 2 * (Nxy - 1), ky = 2 * (Nyaw - 1);
-        double* zxy = rec;                        // [(Nxy+1)][v,a][2]
-        double* zyaw = rec + 4 * (Nxy + 1);       // [(Nyaw+1)][v,a]
-        wg.pfor(kx + ky + 6, [&](int t) {
-            if (t < kx) {
-                double a0, a1;
-                stridedDot<true>(Wt_xy + t, kx, nbx, bxy, 2, a0, a1);
-                zxy[(t + 2) * 2] = a0;            // row t = (knot 1 + t/2, v|a)  ->  slot (knot*2 + w) = t + 2
-                zxy[(t + 2) * 2 + 1] = a1;
-            } else if (t < kx + ky) {
-                const int r = t - kx;
-                double a0, a1;
-                stridedDot<false>(Wt_yaw + r, ky, nby, byaw, 1, a0, a1);
-                zyaw[r + 2] = a0;
-            } else {
-                const int u = t - kx - ky;
-                if (u == 0) { zxy[0] = bxy[2]; zxy[1] = bxy[3]; }
-                else if (u == 1) { zxy[2] = bxy[4]; zxy[3] = bxy[5]; }
-                else if (u == 2) { zxy[(2 * Nxy) * 2] = bxy[(Nxy + 3) * 2]; zxy[(2 * Nxy) * 2 + 1] = bxy[(Nxy + 3) * 2 + 1]; }
-                else if (u == 3) { zxy[(2 * Nxy + 1) * 2] = bxy[(Nxy + 4) * 2]; zxy[(2 * Nxy + 1) * 2 + 1] = bxy[(Nxy + 4) * 2 + 1]; }
-                else if (u == 4) { zyaw[0] = byaw[1]; zyaw[1] = byaw[2]; }
-                else { zyaw[2 * Nyaw] = byaw[Nyaw + 3]; zyaw[2 * Nyaw + 1] = byaw[Nyaw + 4]; }
-            }
-        });
-        // quintic Hermite expansion of every piece from its end states (normalised time), then c_k = c~_k T^-k
-        wg.pfor(2 * Nxy + Nyaw, [&](int t) {
-            double p0, p1, v0, a0, v1, a1, it_;
-            double* out;
+        const long long tsub1 = wg.clock();
+        wg.thomas(ttab, false, zyaw + 2, Nyaw - 1, zxy + 4, Nxy - 1);
+        if (sub_t) { sub_t[0] += tsub1 - tsub_start; sub_t[1] += wg.clock() - tsub1; }
+    }
+
+    // ------------------------------------------------------------------ MINCO generate, part 2, fused with the jerk terms
+    // One lane per (piece, dimension): quintic Hermite expansion from the piece's end states (normalised time), c_k = c~_k T^-k,
+    // the piece's share of the jerk energy and of its direct T-derivative (se2traj.hpp:697-710, 736-745), and G <- jerk_w dJ/dc
+    // (:722-734) -- the coefficients are still in registers.  Two more lanes fill the sample-time tables.
+    // out[0] = energy_xy + energy_yaw, out[1] = sum_i gdT_xy(i), out[2] = sum_i gdT_yaw(i)   (unscaled)
+    UPH_HD void expand(const double* xin, double jerk_w, double out[3]) {
+        const long long t0 = wg.clock();
+        const double Tx = Txy, Ty = Tyaw, itx = 1.0 / Tx, ity = 1.0 / Ty;
+        const double* zxy = rec;
+        const double* zyaw = rec + 4 * (Nxy + 1);
+        const int np = 2 * Nxy + Nyaw;
+        wg.template sum<3>(np + 2, out, [&](int t, double* acc) {
+            if (t >= np) { fillTimes(t - np); return; }
+            double p0, p1, v0, a0, v1, a1, it_, T1;
+            double *oc, *og;
             int os;
-            if (t < 2 * Nxy) {
+            const bool isxy = t < 2 * Nxy;
+            if (isxy) {
                 const int i = t >> 1, dd = t & 1;
-                p0 = bxy[knotCol(i, Nxy) * 2 + dd]; p1 = bxy[knotCol(i + 1, Nxy) * 2 + dd];
-                v0 = zxy[(2 * i) * 2 + dd]; a0 = zxy[(2 * i + 1) * 2 + dd]; v1 = zxy[(2 * i + 2) * 2 + dd]; a1 = zxy[(2 * i + 3) * 2 + dd];
-                out = cxy + 12 * i + dd; os = 2; it_ = itx;
+                p0 = knotPos(xin, i, dd); p1 = knotPos(xin, i + 1, dd);
+                v0 = zxy[4 * i + dd]; a0 = zxy[4 * i + 2 + dd]; v1 = zxy[4 * i + 4 + dd]; a1 = zxy[4 * i + 6 + dd];
+                oc = cxy + 12 * i + dd; og = Gxy + 12 * i + dd; os = 2; it_ = itx; T1 = Tx;
             } else {
                 const int m = t - 2 * Nxy;
-                p0 = byaw[knotCol(m, Nyaw)]; p1 = byaw[knotCol(m + 1, Nyaw)];
+                p0 = knotPos(xin, m, 2); p1 = knotPos(xin, m + 1, 2);
                 v0 = zyaw[2 * m]; a0 = zyaw[2 * m + 1]; v1 = zyaw[2 * m + 2]; a1 = zyaw[2 * m + 3];
-                out = cyaw + 6 * m; os = 1; it_ = ity;
+                oc = cyaw + 6 * m; og = Gyaw + 6 * m; os = 1; it_ = ity; T1 = Ty;
             }
             const double dl = p1 - p0;
-            const double c3 = 10.0 * dl - 6.0 * v0 - 4.0 * v1 - 1.5 * a0 + 0.5 * a1;
-            const double c4 = -15.0 * dl + 8.0 * v0 + 7.0 * v1 + 1.5 * a0 - a1;
-            const double c5 = 6.0 * dl - 3.0 * v0 - 3.0 * v1 - 0.5 * a0 + 0.5 * a1;
+            const double h3 = 10.0 * dl - 6.0 * v0 - 4.0 * v1 - 1.5 * a0 + 0.5 * a1;
+            const double h4 = -15.0 * dl + 8.0 * v0 + 7.0 * v1 + 1.5 * a0 - a1;
+            const double h5 = 6.0 * dl - 3.0 * v0 - 3.0 * v1 - 0.5 * a0 + 0.5 * a1;
             const double i2 = it_ * it_, i3 = i2 * it_, i4 = i3 * it_, i5 = i4 * it_;
-            out[0] = p0; out[os] = v0 * it_; out[2 * os] = (0.5 * a0) * i2;
-            out[3 * os] = c3 * i3; out[4 * os] = c4 * i4; out[5 * os] = c5 * i5;
+            const double c3 = h3 * i3, c4 = h4 * i4, c5 = h5 * i5;
+            oc[0] = p0; oc[os] = v0 * it_; oc[2 * os] = (0.5 * a0) * i2;
+            oc[3 * os] = c3; oc[4 * os] = c4; oc[5 * os] = c5;
+            const double T2 = T1 * T1, T3 = T2 * T1, T4 = T2 * T2, T5 = T4 * T1;
+            og[0] = 0.0; og[os] = 0.0; og[2 * os] = 0.0;
+            og[3 * os] = jerk_w * (72.0 * c3 * T1 + 144.0 * c4 * T2 + 240.0 * c5 * T3);
+            og[4 * os] = jerk_w * (144.0 * c3 * T2 + 384.0 * c4 * T3 + 720.0 * c5 * T4);
+            og[5 * os] = jerk_w * (240.0 * c3 * T3 + 720.0 * c4 * T4 + 1440.0 * c5 * T5);
+            const double d33 = c3 * c3, d43 = c4 * c3, d44 = c4 * c4, d53 = c5 * c3, d54 = c5 * c4, d55 = c5 * c5;
+            acc[0] += 36.0 * d33 * T1 + 144.0 * d43 * T2 + 192.0 * d44 * T3 + 240.0 * d53 * T3 + 720.0 * d54 * T4 + 720.0 * d55 * T5;
+            const double gT = 36.0 * d33 + 288.0 * d43 * T1 + 576.0 * d44 * T2 + 720.0 * d53 * T2 + 2880.0 * d54 * T3 + 3600.0 * d55 * T4;
+            if (isxy) acc[1] += gT; else acc[2] += gT;
         });
-        if (sub_t) { sub_t[0] += tsub0 - tsub_start; sub_t[1] += wg.clock() - tsub0; }
+        if (sub_t) sub_t[2] += wg.clock() - t0;
     }
 
     // ------------------------------------------------------------------ per-sample kinematics + terrain
@@ -354,9 +308,10 @@ struct Solver {
         for (int k = 0; k < 6; k++) { yaw += cy[k] * S_.y0[k]; dyaw += cy[k] * S_.y1[k]; d2yaw += cy[k] * S_.y2[k]; }
         S_.yaw = yaw; S_.dyaw = dyaw; S_.d2yaw = d2yaw;
         const double yawn = normSO2(yaw);                               // :767-770
-        sincos(yaw, &S_.syaw, &S_.cyaw);                                // one argument reduction for both
-        double cw = S_.cyaw, sw = S_.syaw;                              // cos/sin of the wrapped yaw (uneven_map.h:329-330)
-        if (yawn != yaw) sincos(yawn, &sw, &cw);
+        sincosFast(yaw, S_.syaw, S_.cyaw);                              // one argument reduction for both
+        // cos / sin of the WRAPPED yaw (uneven_map.h:329-330): yawn = yaw - 2 pi k differs from yaw by a rounding of ~1e-16 |yaw|,
+        // so the same pair serves (the reference evaluates cos / sin a second time on the wrapped value)
+        const double cw = S_.cyaw, sw = S_.syaw;
         S_.v_norm = sqrt(S_.vel[0] * S_.vel[0] + S_.vel[1] * S_.vel[1]);   // :771-775
         S_.lon_acc = S_.acc[0] * S_.cyaw + S_.acc[1] * S_.syaw;
         S_.lat_acc = S_.acc[0] * (-S_.syaw) + S_.acc[1] * S_.cyaw;
@@ -374,29 +329,33 @@ struct Solver {
     UPH_HD double augCost(double h, double lm) const { return h * (lm + 0.5 * rho * h); }   // alm_traj_opt.h:153-163
     UPH_HD double augGrad(double h, double lm) const { return rho * h + lm; }
 
-    // the sample's own contribution to the gradient blocks it touches (alm_traj_opt.cpp:969-979):
-    //   rec[2k+d]  = beta0_k grad_p[d] + beta1_k grad_v[d] + beta2_k grad_a[d]     -> gdCxy block of its xy piece
-    //   rec[12+k]  = beta0_k(u) grad_yaw + beta1_k(u) grad_dyaw                    -> gdCyaw block of its yaw piece (grad_d2yaw == 0, Q8)
+    // What the sample leaves for the per-piece reduction (alm_traj_opt.cpp:969-979):
+    //   rec[0..5]  = grad_p, grad_v, grad_a (2 each): scatterChunk applies the basis weights beta0/1/2 of the sample's in-piece time,
+    //                which depend on j only and are tabulated once per evaluation (wtab, written by the 17 samples of piece 0)
+    //   rec[6+k]   = beta0_k(u) grad_yaw + beta1_k(u) grad_dyaw   -> gdCyaw block of its yaw piece (grad_d2yaw == 0, Q8)
     //   rtag       = that yaw piece (int32)
-    UPH_HD void putRec(int slot, int j, const double gp_[2], const double gv_[2], const double ga_[2], double gyaw, double gdyaw, const Kin& k) {
-        (void)j;
-        const double s1 = k.s1, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;     // beta0/1/2 of alm_traj_opt.cpp:738-740, rebuilt from s1
-        const double b0[6] = {1.0, s1, s2, s3, s4, s5};
-        const double b1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
-        const double b2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            rec[(2 * q) * CHP + slot] = (b0[q] * gp_[0] + b1[q] * gv_[0] + b2[q] * ga_[0]);
-            rec[(2 * q + 1) * CHP + slot] = (b0[q] * gp_[1] + b1[q] * gv_[1] + b2[q] * ga_[1]);
-        }
+    UPH_HD void putRec(int slot, int i, int j, const double gp_[2], const double gv_[2], const double ga_[2], double gyaw, double gdyaw, const Kin& k) {
+        rec[0 * CHP + slot] = gp_[0]; rec[1 * CHP + slot] = gp_[1];
+        rec[2 * CHP + slot] = gv_[0]; rec[3 * CHP + slot] = gv_[1];
+        rec[4 * CHP + slot] = ga_[0]; rec[5 * CHP + slot] = ga_[1];
         const double u1 = k.u, u2 = u1 * u1, u3 = u2 * u1, u4 = u2 * u2, u5 = u4 * u1;
-        rec[12 * CHP + slot] = gyaw;
-        rec[13 * CHP + slot] = (u1 * gyaw + gdyaw);
-        rec[14 * CHP + slot] = (u2 * gyaw + 2.0 * u1 * gdyaw);
-        rec[15 * CHP + slot] = (u3 * gyaw + 3.0 * u2 * gdyaw);
-        rec[16 * CHP + slot] = (u4 * gyaw + 4.0 * u3 * gdyaw);
-        rec[17 * CHP + slot] = (u5 * gyaw + 5.0 * u4 * gdyaw);
+        rec[6 * CHP + slot] = gyaw;
+        rec[7 * CHP + slot] = (u1 * gyaw + gdyaw);
+        rec[8 * CHP + slot] = (u2 * gyaw + 2.0 * u1 * gdyaw);
+        rec[9 * CHP + slot] = (u3 * gyaw + 3.0 * u2 * gdyaw);
+        rec[10 * CHP + slot] = (u4 * gyaw + 4.0 * u3 * gdyaw);
+        rec[11 * CHP + slot] = (u5 * gyaw + 5.0 * u4 * gdyaw);
         rtag[slot] = k.yaw_idx;
+        if (i == 0) {                                    // beta0/1/2 of alm_traj_opt.cpp:738-740 at s1(j), rebuilt from s1 (not kept live across the sample)
+            double* w = wtab + 18 * j;
+            const double s1 = k.s1, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+            w[0] = 1.0; w[1] = 0.0; w[2] = 0.0;
+            w[3] = s1; w[4] = 1.0; w[5] = 0.0;
+            w[6] = s2; w[7] = 2.0 * s1; w[8] = 2.0;
+            w[9] = s3; w[10] = 3.0 * s2; w[11] = 6.0 * s1;
+            w[12] = s4; w[13] = 4.0 * s3; w[14] = 12.0 * s2;
+            w[15] = s5; w[16] = 5.0 * s4; w[17] = 20.0 * s3;
+        }
     }
 
     // one constraint sample of calConstrainCostGrad (alm_traj_opt.cpp:716-988).  acc[0] += cost, acc[1] += gdTxy part, acc[2] += gdTyaw part
@@ -531,7 +490,7 @@ struct Solver {
         grad_p[0] += grad_se2[0]; grad_p[1] += grad_se2[1];
         grad_yaw += grad_se2[2];
         // scatter terms (:966-985): the C-blocks are reduced per piece in scatter(); the T parts are summed here
-        putRec(slot, j, grad_p, grad_v, grad_a, grad_yaw, grad_dyaw, k);
+        putRec(slot, i, j, grad_p, grad_v, grad_a, grad_yaw, grad_dyaw, k);
         tx += ((grad_p[0] * k.vel[0] + grad_p[1] * k.vel[1]) + (grad_v[0] * k.acc[0] + grad_v[1] * k.acc[1]) +
                (grad_a[0] * k.jer[0] + grad_a[1] * k.jer[1])) * alpha;
         const double yawdot = (grad_yaw * k.dyaw + grad_dyaw * k.d2yaw);
@@ -555,55 +514,19 @@ struct Solver {
 #pragma unroll
         for (int q = 0; q < 3; q++) gse2[q] = omega * k.gs[q] * sigma * 2.0;
         const double zero2[2] = {0, 0};
-        putRec(slot, j, gse2, zero2, zero2, gse2[2], 0.0, k);
+        putRec(slot, i, j, gse2, zero2, zero2, gse2[2], 0.0, k);
         acc[0] += user_cost;
         acc[1] += user_cost / K + (gse2[0] * k.vel[0] + gse2[1] * k.vel[1]) * alpha + (gse2[2] * k.dyaw) * (alpha + i);
         acc[2] += -(gse2[2] * k.dyaw) * k.yaw_idx;
     }
 
-    // ------------------------------------------------------------------ jerk energy and its direct T-derivative (se2traj.hpp:697-710, 736-745)
-    // acc[0] += energy_xy + energy_yaw, acc[1] += sum_i gdT_xy(i), acc[2] += sum_i gdT_yaw(i)   (unscaled)
-    UPH_HD void jerkSums(double out[3]) {
-        const double Tx = Txy, Ty = Tyaw;
-        wg.template sum<3>(Nxy + Nyaw, out, [&](int t, double* acc) {
-            double T1, c3[2], c4[2], c5[2];
-            int D;
-            if (t < Nxy) {
-                T1 = Tx; D = 2;
-                const double* c = cxy + 12 * t;
-                c3[0] = c[6]; c3[1] = c[7]; c4[0] = c[8]; c4[1] = c[9]; c5[0] = c[10]; c5[1] = c[11];
-            } else {
-                T1 = Ty; D = 1;
-                const double* c = cyaw + 6 * (t - Nxy);
-                c3[0] = c[3]; c3[1] = 0; c4[0] = c[4]; c4[1] = 0; c5[0] = c[5]; c5[1] = 0;
-            }
-            const double T2 = T1 * T1, T3 = T2 * T1, T4 = T2 * T2, T5 = T4 * T1;
-            double d33 = 0, d43 = 0, d44 = 0, d53 = 0, d54 = 0, d55 = 0;
-            for (int q = 0; q < D; q++) {
-                d33 += c3[q] * c3[q]; d43 += c4[q] * c3[q]; d44 += c4[q] * c4[q];
-                d53 += c5[q] * c3[q]; d54 += c5[q] * c4[q]; d55 += c5[q] * c5[q];
-            }
-            const double energy = 36.0 * d33 * T1 + 144.0 * d43 * T2 + 192.0 * d44 * T3 + 240.0 * d53 * T3 + 720.0 * d54 * T4 + 720.0 * d55 * T5;
-            const double gT = 36.0 * d33 + 288.0 * d43 * T1 + 576.0 * d44 * T2 + 720.0 * d53 * T2 + 2880.0 * d54 * T3 + 3600.0 * d55 * T4;
-            acc[0] += energy;
-            if (t < Nxy) acc[1] += gT; else acc[2] += gT;
-        });
-    }
-    UPH_HD double jerkGradC(double c3, double c4, double c5, int k, double T1) const {   // se2traj.hpp:722-734
-        const double T2 = T1 * T1, T3 = T2 * T1, T4 = T2 * T2, T5 = T4 * T1;
-        if (k == 5) return 240.0 * c3 * T3 + 720.0 * c4 * T4 + 1440.0 * c5 * T5;
-        if (k == 4) return 144.0 * c3 * T2 + 384.0 * c4 * T3 + 720.0 * c5 * T4;
-        if (k == 3) return 72.0 * c3 * T1 + 144.0 * c4 * T2 + 240.0 * c5 * T3;
-        return 0.0;
-    }
-
     // ------------------------------------------------------------------ per-piece reduction of the sample records into dK/dc
-    // G = jerk_w * dJ/dc  +  sum over samples of (beta0 (x) grad_p + beta1 (x) grad_v + beta2 (x) grad_a)   (:969-979).
+    // G = jerk_w * dJ/dc (expand)  +  sum over samples of (beta0 (x) grad_p + beta1 (x) grad_v + beta2 (x) grad_a)   (:969-979).
     // Samples are produced in chunks of CH (= workgroup size) records; each chunk is folded into G right away.
     // sample-time tables of calConstrainCostGrad, built by the reference's own accumulations so that the roundings agree:
     //   bt[i] = base_time of piece i       (base += T1(i), alm_traj_opt.cpp:709,989)       i = 0..Nxy
     //   bt[Nxy+1+j] = in-piece time s1     (s1 += step, :713-714,987; Q2)                  j = 0..K
-    // They live in the beta buffers, which are dead from the end of generate() until adjoint() writes gamma there.
+    // Alive from expand() until adjoint() writes gamma into the same words.
     UPH_HD void fillTimes(int u) {
         if (u == 0) {
             double base = 0.0;
@@ -614,24 +537,9 @@ struct Solver {
             for (int j = 0; j <= K; j++) { bt[Nxy + 1 + j] = s1; s1 += step; }
         }
     }
-    UPH_HD void initG(double jerk_w) {
-        const int ng = 12 * Nxy + 6 * Nyaw;
-        wg.pfor(ng + 2, [&](int t) {
-            if (t >= ng) fillTimes(t - ng);
-            else if (t < 12 * Nxy) {
-                const int i = t / 12, r = t - 12 * i, k = r >> 1, dd = r & 1;
-                const double* c = cxy + 12 * i;
-                Gxy[t] = jerk_w * jerkGradC(c[6 + dd], c[8 + dd], c[10 + dd], k, Txy);
-            } else {
-                const int r = t - 12 * Nxy, m = r / 6, k = r - 6 * m;
-                const double* c = cyaw + 6 * m;
-                Gyaw[r] = jerk_w * jerkGradC(c[3], c[4], c[5], k, Tyaw);
-            }
-        });
-    }
     // fold the records of samples [s0, s0+cnt) into G: one lane per output element -- (xy piece, k, dim) and (yaw piece, k) --
-    // each summing the ready-made contributions of its <= K+1 (xy) or <= 4(K+1) candidate (yaw) samples in slot order
-    // (fixed order, no atomics).  LDS reads go out in batches so that they overlap.
+    // each summing the contributions of its <= K+1 (xy) or <= 4(K+1) candidate (yaw) samples in slot order (fixed order, no
+    // atomics).  LDS reads go out in batches so that they overlap.
     UPH_HD void scatterChunk(int s0, int cnt) {
         const int K1 = K + 1;
         const float xr = (float)Nxy / (float)Nyaw;          // xy pieces per yaw piece
@@ -643,18 +551,24 @@ struct Solver {
         if (m1 > Nyaw - 1) m1 = Nyaw - 1;
         wg.pfor(nxyt + 6 * (m1 - m0 + 1), [&](int t) {
             if (t < nxyt) {
-                const int i = i0 + t / 12, r = t % 12;
+                const int i = i0 + t / 12, r = t % 12, q = r >> 1, dd = r & 1;
                 int ja = i * K1 - s0, jb = ja + K1;          // slots of this piece inside the chunk
+                const int jo = ja;                           // slot - jo = the sample's in-piece index j
                 if (ja < 0) ja = 0;
                 if (jb > cnt) jb = cnt;
-                const double* rr = rec + r * CHP;
+                const double* rp = rec + dd * CHP;           // grad_p[dd], grad_v[dd] two rows on, grad_a[dd] four
+                const double* wq = wtab + 3 * q - 18 * jo;   // weights of (j, q) at wq[18 * slot]
                 double a = 0.0;
                 for (int sb_ = ja; sb_ < jb; sb_ += UPH_SC_XB) {
-                    double e[UPH_SC_XB];
+                    double e0[UPH_SC_XB], e1[UPH_SC_XB], e2[UPH_SC_XB], w0[UPH_SC_XB], w1[UPH_SC_XB], w2[UPH_SC_XB];
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_XB; u++) e[u] = rr[sb_ + u < jb ? sb_ + u : jb - 1];
+                    for (int u = 0; u < UPH_SC_XB; u++) {
+                        const int sl = sb_ + u < jb ? sb_ + u : jb - 1;
+                        e0[u] = rp[sl]; e1[u] = rp[2 * CHP + sl]; e2[u] = rp[4 * CHP + sl];
+                        w0[u] = wq[18 * sl]; w1[u] = wq[18 * sl + 1]; w2[u] = wq[18 * sl + 2];
+                    }
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_XB; u++) a += sb_ + u < jb ? e[u] : 0.0;
+                    for (int u = 0; u < UPH_SC_XB; u++) a += sb_ + u < jb ? (w0[u] * e0[u] + w1[u] * e1[u] + w2[u] * e2[u]) : 0.0;
                 }
                 Gxy[12 * i + r] += a;
             } else {
@@ -670,7 +584,7 @@ struct Solver {
                 if (sa < 0) sa = 0;
                 if (sb > cnt) sb = cnt;
                 if (sb < sa) sb = sa;
-                const double* rv = rec + (12 + k) * CHP;
+                const double* rv = rec + (6 + k) * CHP;
                 double a = 0.0;
                 for (int s8 = sa; s8 < sb; s8 += UPH_SC_YB) {
                     int tg_[UPH_SC_YB];
@@ -686,55 +600,42 @@ struct Solver {
     }
 
     // ------------------------------------------------------------------ adjoint: (dK/dc, direct dK/dT sums) -> gradient w.r.t. (q, T)
-    // On return gamxy/gamyaw hold M^T (G T^-k); returns sum_i dW/dT_i for xy and yaw (without the direct parts).
+    // calGradCTtoQT (se2traj.hpp:751-816) through the knot system.  On return gamxy / gamyaw hold gamma = M^T (G T^-k) laid out
+    // like beta; chain_xy / chain_yaw = sum_i dW/dT_i without the direct parts (header comment).
     UPH_HD void adjoint(double& chain_xy, double& chain_yaw) {
         const double Tx = Txy, Ty = Tyaw, itx = 1.0 / Txy, ity = 1.0 / Tyaw;
         const long long ta0 = wg.clock();
+        const int nbx = Nxy + 5, nby = Nyaw + 5;
+        const int nvec = 2 * nbx + nby;
+        double* gwxy = rec;                              // [Nxy-1][v,a][2]   (records are consumed by scatterChunk before adjoint runs)
+        double* gwyaw = gwxy + 4 * (Nxy - 1);            // [Nyaw-1][v,a]
+        double* gdir = gwyaw + 2 * (Nyaw - 1);           // [nvec] direct contributions, laid out like gamma
+        // One lane per (knot, dimension): transposed Hermite expansion of G T^-k -- every knot collects from the piece it opens and
+        // the piece it closes; interior (v, a) go to the transposed knot solve, everything that is itself an entry of beta (all
+        // positions, the end knots' V and A) straight to its column -- plus the opened piece's share of -sum_k k c_k / T * G_k.
         double ch[2];
-        // -sum_{i,k} k c_ik / T * G_ik, and G <- G T^-k (in place; each element is touched by exactly one lane)
-        wg.template sum<2>(12 * Nxy + 6 * Nyaw, ch, [&](int t, double* acc) {
-            if (t < 12 * Nxy) {
-                const int k = (t % 12) >> 1;
-                const double gv = Gxy[t];
-                acc[0] += -(double)k * cxy[t] * itx * gv;
-                double s = 1.0;
-                for (int q = 0; q < k; q++) s *= itx;
-                Gxy[t] = gv * s;
-            } else {
-                const int r = t - 12 * Nxy, k = r % 6;
-                const double gv = Gyaw[r];
-                acc[1] += -(double)k * cyaw[r] * ity * gv;
-                double s = 1.0;
-                for (int q = 0; q < k; q++) s *= ity;
-                Gyaw[r] = gv * s;
-            }
-        });
-        const int nbx = Nxy + 5, nby = Nyaw + 5, kx = 2 * (Nxy - 1), ky = 2 * (Nyaw - 1);
-        const int ncol = nbx + nby, nvec = 2 * nbx + nby;
-        const int mvch = wg.size() / ncol < 1 ? 1 : (wg.size() / ncol > MV_CHUNKS ? MV_CHUNKS : wg.size() / ncol);
-        // transposed Hermite expansion: gradient w.r.t. the knot states (p, v, a); every knot collects from the piece it opens
-        // and the piece it closes.  Interior (v, a) go to the operand vector of the transposed operator, everything that is itself
-        // an entry of beta (all positions, the end knots' V and A) goes straight to its column.
-        double* part = mvp;                              // [mvch][nvec] partial sums of the transposed mat-vec
-        double* gwxy = part + (size_t)mvch * nvec;       // [kx][2]
-        double* gwyaw = gwxy + 2 * kx;                   // [ky]
-        double* gdir = gwyaw + ky;                       // [nvec] direct contributions, laid out like gamma
-        const long long ta1 = wg.clock();
-        wg.pfor(2 * (Nxy + 1) + (Nyaw + 1), [&](int t) {
+        wg.template sum<2>(2 * (Nxy + 1) + (Nyaw + 1), ch, [&](int t, double* acc) {
             const bool isxy = t < 2 * (Nxy + 1);
             const int j = isxy ? (t >> 1) : t - 2 * (Nxy + 1), dd = isxy ? (t & 1) : 0, N = isxy ? Nxy : Nyaw, os = isxy ? 2 : 1;
             const double* G = isxy ? Gxy + dd : Gyaw;
+            const double* c = isxy ? cxy + dd : cyaw;
+            const double it_ = isxy ? itx : ity;
+            const double i2 = it_ * it_, i3 = i2 * it_, i4 = i3 * it_, i5 = i4 * it_;
             double dp = 0.0, dv = 0.0, da = 0.0;
             if (j < N) {
                 const double* gl = G + (size_t)6 * j * os;
-                const double g0 = gl[0], g1 = gl[os], g2 = gl[2 * os], g3 = gl[3 * os], g4 = gl[4 * os], g5 = gl[5 * os];
+                const double* cl = c + (size_t)6 * j * os;
+                const double r1 = gl[os], r2 = gl[2 * os], r3 = gl[3 * os], r4 = gl[4 * os], r5 = gl[5 * os];
+                const double chain = -it_ * (cl[os] * r1 + 2.0 * (cl[2 * os] * r2) + 3.0 * (cl[3 * os] * r3) + 4.0 * (cl[4 * os] * r4) + 5.0 * (cl[5 * os] * r5));
+                if (isxy) acc[0] += chain; else acc[1] += chain;
+                const double g0 = gl[0], g1 = r1 * it_, g2 = r2 * i2, g3 = r3 * i3, g4 = r4 * i4, g5 = r5 * i5;
                 dp += g0 - 10.0 * g3 + 15.0 * g4 - 6.0 * g5;
                 dv += g1 - 6.0 * g3 + 8.0 * g4 - 3.0 * g5;
                 da += 0.5 * g2 - 1.5 * g3 + 1.5 * g4 - 0.5 * g5;
             }
             if (j > 0) {
                 const double* gr_ = G + (size_t)6 * (j - 1) * os;
-                const double g3 = gr_[3 * os], g4 = gr_[4 * os], g5 = gr_[5 * os];
+                const double g3 = gr_[3 * os] * i3, g4 = gr_[4 * os] * i4, g5 = gr_[5 * os] * i5;
                 dp += 10.0 * g3 - 15.0 * g4 + 6.0 * g5;
                 dv += -4.0 * g3 + 7.0 * g4 - 3.0 * g5;
                 da += 0.5 * g3 - g4 + 0.5 * g5;
@@ -743,49 +644,40 @@ struct Solver {
             gd[knotCol(j, N) * os] = dp;
             if (j == 0) { gd[1 * os] = dv; gd[2 * os] = da; }
             else if (j == N) { gd[(N + 3) * os] = dv; gd[(N + 4) * os] = da; }
-            else if (isxy) { gwxy[(2 * (j - 1)) * 2 + dd] = dv; gwxy[(2 * (j - 1) + 1) * 2 + dd] = da; }
+            else if (isxy) { gwxy[4 * (j - 1) + dd] = dv; gwxy[4 * (j - 1) + 2 + dd] = da; }
             else { gwyaw[2 * (j - 1)] = dv; gwyaw[2 * (j - 1) + 1] = da; }
         });
-        // gamma = W^T (knot gradients) as (row-chunk, column) tasks on the [row][col] operator: lanes hold adjacent columns
-        // (coalesced), operator loads go out in unconditional batches, the mvch partial sums of a column meet in LDS.
-        const float inv_ncol = 1.0f / (float)ncol;
-        const int rwx = (kx + mvch - 1) / mvch, rwy = (ky + mvch - 1) / mvch;
-        wg.pfor(ncol * mvch, [&](int t) {
-            int q = (int)(((float)t + 0.5f) * inv_ncol);       // t / ncol without an integer division (t < 2^16)
-            int c = t - q * ncol;
-            if (c < 0) { q--; c += ncol; }
-            if (c >= ncol) { q++; c -= ncol; }
-            if (c < nbx) {
-                const int r0 = q * rwx, r1 = (r0 + rwx < kx) ? r0 + rwx : kx;
-                double a0 = 0.0, a1 = 0.0;
-                if (r1 > r0) stridedDot<true>(Wr_xy + (size_t)r0 * nbx + c, nbx, r1 - r0, gwxy + 2 * r0, 2, a0, a1);
-                part[(size_t)q * nvec + 2 * c] = a0;
-                part[(size_t)q * nvec + 2 * c + 1] = a1;
-            } else {
-                const int cy = c - nbx;
-                const int r0 = q * rwy, r1 = (r0 + rwy < ky) ? r0 + rwy : ky;
-                double a0 = 0.0, a1 = 0.0;
-                if (r1 > r0) stridedDot<false>(Wr_yaw + (size_t)r0 * nby + cy, nby, r1 - r0, gwyaw + r0, 1, a0, a1);
-                part[(size_t)q * nvec + 2 * nbx + cy] = a0;
-            }
-        });
+        const long long ta1 = wg.clock();
+        // lambda = M^-T (knot gradients) by the transposed block sweeps, in place
+        wg.thomas(ttab, true, gwyaw, Nyaw - 1, gwxy, Nxy - 1);
         const long long ta2 = wg.clock();
-        wg.pfor(nvec, [&](int t) {
-            double a = gdir[t];
-            for (int q = 0; q < mvch; q++) a += part[(size_t)q * nvec + t];
-            if (t < 2 * nbx) gamxy[t] = a; else gamyaw[t - 2 * nbx] = a;
+        // gamma = R^T lambda + direct parts: a way-point / end position p_k enters r_{k-1}, r_k, r_{k+1}; the end states enter r_1
+        // (- A z_0) and r_{N-1} (- C z_N).  The four V / A columns also give <gamma, d b~/dT> (V scales with T, A with T^2).
+        double hh[2];
+        wg.template sum<2>(nvec, hh, [&](int t, double* acc) {
+            const bool isxy = t < 2 * nbx;
+            const int col = isxy ? (t >> 1) : t - 2 * nbx, dd = isxy ? (t & 1) : 0, N = isxy ? Nxy : Nyaw;
+            const int ks = isxy ? 4 : 2, cs = isxy ? 2 : 1;
+            const double* lam = isxy ? gwxy + dd : gwyaw;
+            const double T1 = isxy ? Tx : Ty;
+            const double* h0 = isxy ? hd + dd : hd + 12;
+            const double* h1 = isxy ? hd + 6 + dd : hd + 15;
+            auto L0 = [&](int j) { return (j >= 1 && j <= N - 1) ? lam[(j - 1) * ks] : 0.0; };
+            auto L1 = [&](int j) { return (j >= 1 && j <= N - 1) ? lam[(j - 1) * ks + cs] : 0.0; };
+            double a = gdir[t], hT = 0.0;
+            if (col == 1) { a += 8.0 * L0(1) + 7.0 * L1(1); hT = a * h0[cs]; }                             // V0: (-A^T lambda_1)[0]
+            else if (col == 2) { a += L0(1) + L1(1); hT = a * (2.0 * T1 * h0[2 * cs]); }                   // A0: (-A^T lambda_1)[1]
+            else if (col == N + 3) { a += -8.0 * L0(N - 1) + 7.0 * L1(N - 1); hT = a * h1[cs]; }           // VN: (-C^T lambda_{N-1})[0]
+            else if (col == N + 4) { a += L0(N - 1) - L1(N - 1); hT = a * (2.0 * T1 * h1[2 * cs]); }       // AN: (-C^T lambda_{N-1})[1]
+            else {
+                const int k = col == 0 ? 0 : (col == N + 2 ? N : col - 2);
+                a += 20.0 * ((L0(k - 1) - L0(k)) - (L0(k) - L0(k + 1))) - 15.0 * (L1(k - 1) - L1(k + 1));
+            }
+            if (isxy) { gamxy[t] = a; acc[0] += hT; } else { gamyaw[t - 2 * nbx] = a; acc[1] += hT; }
         });
-        if (sub_t) { sub_t[2] += ta1 - ta0; sub_t[3] += ta2 - ta1; sub_t[4] += wg.clock() - ta2; }
-        // <gamma, d b~/dT>: only the head/tail V (x1) and A (x 2T) entries depend on T
-        double hx_ = 0.0, hy_ = 0.0;
-        for (int dd = 0; dd < 2; dd++) {
-            hx_ += gamxy[1 * 2 + dd] * hd[0 + (2 + dd)] + gamxy[2 * 2 + dd] * (2.0 * Tx * hd[0 + (4 + dd)]) +
-                   gamxy[(Nxy + 3) * 2 + dd] * hd[6 + (2 + dd)] + gamxy[(Nxy + 4) * 2 + dd] * (2.0 * Tx * hd[6 + (4 + dd)]);
-        }
-        hy_ += gamyaw[1] * hd[13] + gamyaw[2] * (2.0 * Ty * hd[14]) + gamyaw[Nyaw + 3] * hd[16] +
-               gamyaw[Nyaw + 4] * (2.0 * Ty * hd[17]);
-        chain_xy = ch[0] + hx_;
-        chain_yaw = ch[1] + hy_;
+        if (sub_t) { sub_t[4] += ta1 - ta0; sub_t[5] += ta2 - ta1; sub_t[6] += wg.clock() - ta2; }
+        chain_xy = ch[0] + hh[0];
+        chain_yaw = ch[1] + hh[1];
     }
 
     UPH_HD void evalConsts() {
@@ -802,14 +694,13 @@ struct Solver {
         long long t0 = wg.clock();
         if (t_last_eval_end) cyc[5] += t0 - t_last_eval_end;      // from the end of the previous evaluation (or of the two-loop) to here
         generate(xin);
-        long long t1 = wg.clock(); cyc[0] += t1 - t0;
         const double tau = xin[0];
-        double js[3];
-        jerkSums(js);
-        last_jerk = js[0];
         const double jw = P.use_scaling ? scale_trick_jerk * scale_fx : scale_fx;      // :308-310, 322-332
+        double js[3];
+        expand(xin, jw, js);
+        long long t1 = wg.clock(); cyc[0] += t1 - t0;
+        last_jerk = js[0];
         const double jerk_cost = P.use_scaling ? js[0] * scale_fx * scale_trick_jerk : js[0] * scale_fx;
-        initG(jw);
         evalConsts();
         double sm[3] = {0.0, 0.0, 0.0};
         for (int s0 = 0; s0 < S; s0 += CH) {
@@ -850,8 +741,7 @@ struct Solver {
         const double dTau = getTtoTauGrad(tau);
         // objective scale (:365-370, 507-519, 627-653): jerk + rho_ter*int sigma^2 + rho_T*T, no scale_trick_jerk
         double js[3];
-        jerkSums(js);
-        initG(1.0);
+        expand(x0, 1.0, js);
         double sm[3] = {0.0, 0.0, 0.0};
         for (int s0 = 0; s0 < S; s0 += CH) {
             const int cnt = S - s0 < CH ? S - s0 : CH;
@@ -1098,18 +988,12 @@ struct Solver {
                 // and xp / gp before the exit tests is harmless: every exit below ends this L-BFGS call.
                 double* sc = lm_s + (size_t)end * n;
                 double* yc = lm_y + (size_t)end * n;
-#if UPH_COMPACT_DIRECTION
-                const bool compact = bd.compact != 0;
-#endif
                 double r5[5], mx2[2];
                 wg.template sumMax<5, 2>(n, r5, mx2, [&](int i, double* acc, double* mx) {
                     const double xv = x[i], gv = g[i], xo = xp[i], go = gp[i];
                     const double sv = xv - xo, yv = gv - go;
                     mx[0] = dmax(mx[0], fabs(gv)); mx[1] = dmax(mx[1], fabs(xv));
                     sc[i] = sv; yc[i] = yv;
-#if UPH_COMPACT_DIRECTION
-                    if (compact) { lm_st[(size_t)i * m + end] = sv; lm_yt[(size_t)i * m + end] = yv; rec[i] = yv; }   // transposed copy; y_new stays in LDS for the Gram column
-#endif
                     acc[0] += yv * sv; acc[1] += yv * yv; acc[2] += sv * sv; acc[3] += go * go; acc[4] += gv * gv;
                     xp[i] = xv; gp[i] = gv;
                     d[i] = -gv;
@@ -1144,10 +1028,6 @@ struct Solver {
                     // two-loop recursion (lbfgs.hpp:687-710): a serial chain of 2*bound dot/axpy steps over the history in HBM
                     const long long tq = wg.clock();
                     cyc[7] += tq - t_last_eval_end;                 // end of evaluation -> start of the two-loop
-#if UPH_COMPACT_DIRECTION
-                    if (compact) wg.direction(d, g, rec, n, lm_s, lm_y, lm_st, lm_yt, gm_sy, gm_ys, gm_yy, lm_ys, rec + ((n + 1) & ~1), pf + MAX_PAST, m, end, bound, ys / yy);
-                    else
-#endif
                     wg.twoLoop(d, g, n, lm_s, lm_y, lm_ys, pf + MAX_PAST, rec, m, end, bound, ys / yy);   // (the record buffer is idle here: it parks the alphas)
                     dginit = wg.bcast(pf[MAX_PAST]);                // g . d, left by the two-loop
                     t_last_eval_end = wg.clock();
@@ -1185,7 +1065,7 @@ struct Solver {
         wg.pfor(1, [&](int) {
             st.T_xy = Txy; st.T_yaw = Tyaw; st.jerk_cost = last_jerk; st.scale_fx = scale_fx; st.rho = rho;
             st.evals = evals; st.hist_reads = hist_reads;
-            for (int q = 0; q < 8; q++) st.cyc[q] = cyc[q];
+            for (int q = 0; q < 16; q++) st.cyc[q] = cyc[q];
         });
     }
 
@@ -1239,28 +1119,28 @@ struct Solver {
 
     // diagnostic: shader-clock ticks per call of the phases of one evaluation (averaged over `reps`), written to st.cyc[0..7]
     UPH_HD void microbench(TrajState& st, int reps) {
-        // phase-level: 0 generate  1 jerkSums  2 initG  3 sampleEval chunk 0 (sum<3>)  4 scatterChunk(0)  5 adjoint  6 sum<1> over n  7 total
+        // phase-level: 0 generate (knot states)  1 expand (Hermite + jerk + G)  2 evalConsts  3 sampleEval chunk 0 (sum<3>)  4 scatterChunk(0)
+        // 5 adjoint  6 L-BFGS bookkeeping  7 total; 8.. sub-steps (sub_t)
         const double* gx0 = bd.x + td.off_x;
         rho = wg.bcast(st.rho); scale_fx = wg.bcast(st.scale_fx);
-        wg.pfor(n, [&](int t) { x[t] = gx0[t]; d[t] = 0.5; });
+        wg.pfor(n, [&](int t) { x[t] = gx0[t]; d[t] = 0.5; xp[t] = gx0[t]; gp[t] = 0.25; });
         long long a[9];
-        long long sub[5] = {0, 0, 0, 0, 0};
+        long long sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         sub_t = sub;
         double acc = 0.0, js[3], part[3], c1, c2;
         const int cnt = S < CH ? S : CH;
         a[0] = wg.clock();
         for (int r = 0; r < reps; r++) generate(x);
         a[1] = wg.clock();
-        for (int r = 0; r < reps; r++) { jerkSums(js); acc += js[0]; }
+        for (int r = 0; r < reps; r++) { expand(x, 1.0, js); acc += js[0]; }
         a[2] = wg.clock();
-        for (int r = 0; r < reps; r++) initG(1.0);
+        for (int r = 0; r < reps; r++) evalConsts();
         a[3] = wg.clock();
-        evalConsts();
         for (int r = 0; r < reps; r++) { wg.template sum<3>(cnt, part, [&](int t, double* ac) { sampleEval(t, t, ac); }); acc += part[0]; }
         a[4] = wg.clock();
         for (int r = 0; r < reps; r++) scatterChunk(0, cnt);
         a[5] = wg.clock();
-        for (int r = 0; r < reps; r++) { initG(1.0); adjoint(c1, c2); acc += c1 + c2; }
+        for (int r = 0; r < reps; r++) { adjoint(c1, c2); acc += c1 + c2; }
         a[6] = wg.clock();
         // the L-BFGS bookkeeping of one iteration (between the evaluation and the two-loop), with a moving ring position
         const int m = mem;
@@ -1287,8 +1167,7 @@ struct Solver {
         wg.pfor(1, [&](int) {
             for (int q = 0; q < 7; q++) st.cyc[q] = (a[q + 1] - a[q]) / reps;
             st.cyc[7] = a[7] - a[0];
-            // sub-steps replace the cheap phases in the report: 1 <- generate beta pfor, 2 <- generate mat-vec, 6 <- adjoint chain pass, 7 <- adjoint mat-vec
-            st.cyc[1] = sub[0] / reps; st.cyc[2] = sub[1] / reps; st.cyc[6] = sub[2] / (2 * reps) * 2; st.cyc[7] = sub[3] / reps;
+            for (int q = 0; q < 8; q++) st.cyc[8 + q] = sub[q] / reps;
             st.f = acc;
         });
         sub_t = nullptr;
@@ -1361,9 +1240,8 @@ struct Solver {
             for (int kk = 1; kk <= 5; kk++) { dyaw += kk * tn * c[kk]; tn *= tw; }
             const double yawn = normSO2(yaw);
             double cy_, sy_;
-            sincos(yaw, &sy_, &cy_);
-            double cw = cy_, sw = sy_;
-            if (yawn != yaw) sincos(yawn, &sw, &cw);
+            sincosFast(yaw, sy_, cy_);
+            const double cw = cy_, sw = sy_;
             double tv[7];
             terrainVariables(grid, p[0], p[1], yawn, cw, sw, tv, nullptr);
             const double vnorm = sqrt(v[0] * v[0] + v[1] * v[1]);

@@ -20,10 +20,6 @@
 
 using namespace uph;
 
-// The compact (Byrd-Nocedal-Schnabel) L-BFGS direction (DevWG::directionT) is an experimental build option: correct (all parity
-// tests pass, more accurate than the two-loop) but slower on long histories as implemented (O(b^2) Gram traffic, four register
-// groups per solve step): B = 8192 takes 449 ms against 324 ms with the two-loop.
-// -DUPH_COMPACT_DIRECTION=1 (make COMPACT=1) compiles it in.
 #ifndef UPH_TWOLOOP_PF
 #define UPH_TWOLOOP_PF 5
 #endif
@@ -92,10 +88,16 @@ struct DevWG {
     double* red;
     int tid, lane, wave, par;
     __device__ DevWG(double* scratch) : red(scratch), tid(threadIdx.x), lane(threadIdx.x & 63), wave(uni((int)(threadIdx.x >> 6))), par(0) {}
+    // The lane index, re-read through an opaque barrier at the start of every parallel region: everything derived from it (LDS
+    // addresses, task decompositions) is invariant across the solver's outer loops, so the compiler would otherwise hoist those
+    // computations out of the L-BFGS / ALM loops, keep them live through the register-starved sample code and spill them to
+    // scratch -- a scratch reload (s_waitcnt vmcnt(0), memory latency) in place of a shift and an add.
+    __device__ __forceinline__ int ftid() const { int v = tid; asm volatile("" : "+v"(v)); return v; }
+    __device__ __forceinline__ int flane() const { int v = lane; asm volatile("" : "+v"(v)); return v; }
 
     template <class F>
     __device__ __forceinline__ void pfor(int n, F f) {
-        for (int i = tid; i < n; i += NT) f(i);
+        for (int i = ftid(); i < n; i += NT) f(i);
         __syncthreads();
     }
     __device__ __forceinline__ void sync() { __syncthreads(); }
@@ -111,7 +113,7 @@ struct DevWG {
         double acc[M];
 #pragma unroll
         for (int m = 0; m < M; m++) acc[m] = 0.0;
-        for (int i = tid; i < n; i += NT) f(i, acc);
+        for (int i = ftid(); i < n; i += NT) f(i, acc);
 #pragma unroll
         for (int m = 0; m < M; m++) acc[m] = waveSum(acc[m]);          // DPP row rotations: ~3x cheaper than ds_bpermute shuffles
         double* r = red + par * (NW * MAXM);
@@ -138,7 +140,7 @@ struct DevWG {
         for (int m = 0; m < MS; m++) acc[m] = 0.0;
 #pragma unroll
         for (int m = 0; m < MM; m++) mx[m] = 0.0;
-        for (int i = tid; i < n; i += NT) f(i, acc, mx);
+        for (int i = ftid(); i < n; i += NT) f(i, acc, mx);
 #pragma unroll
         for (int m = 0; m < MS; m++) acc[m] = waveSum(acc[m]);
 #pragma unroll
@@ -184,6 +186,7 @@ struct DevWG {
     __device__ __forceinline__ void twoLoopT(double* d, const double* g, double* dg_out, double* al_lds, int n_, const double* __restrict__ lm_s_, const double* __restrict__ lm_y_,
                                              const double* __restrict__ lm_ys_, int m_, int end_, int bound_, double scale_) {
         const gcptr lm_s = uniG(lm_s_), lm_y = uniG(lm_y_), lm_ys = uniG(lm_ys_);
+        const int lane = flane();
         const int n = uni(n_), m = uni(m_), end = uni(end_), bound = uni(bound_);
         const double scale = uni(scale_);
         double dr[NQ], sr[PF][NQ], yr[PF][NQ], ysr[PF], rysr[PF];
@@ -275,259 +278,82 @@ struct DevWG {
         if (lane == 0) *dg_out = gd;
     }
     // ---------------------------------------------------------------------------------------------------------------------------
-    // L-BFGS direction d = -H g in the compact (Byrd-Nocedal-Schnabel 1994) representation -- algebraically the two-loop recursion
-    // of lbfgs.hpp:687-710 with H0 = gamma I, but without its serial chain of 2 b dot/axpy steps over the history:
-    //     H g = gamma g + S a - gamma Y p,     R p = S^T g,     R^T a = (D + gamma Y^T Y) p - gamma Y^T g,
-    // R = upper triangle of S^T Y in age order, D = diag(s_i . y_i).  Pairs are addressed by age a = 0 (oldest) .. b-1 (newest),
-    // ring slot(a) = (end - b + a) mod m.  Steps:
-    //   1. all waves: u = S^T g, v = Y^T g and the new Gram column r = S^T y_new, z = Y^T y_new -- one lane per pair on the
-    //      TRANSPOSED history (coalesced across pairs, no cross-lane reduction), the element range split over the waves;
-    //   2. wave 0: partials combined, Gram column written (SY, its transpose, YY), then the two triangular solves column-oriented
-    //      (each step: one lane read of the pivot, one multiply, one masked FMA per 64 pairs), YY p accumulated on the fly;
-    //   3. all waves: d = -(gamma g + S a - gamma Y p), one lane per element on the row-major history, and g . d.
-    // Measured against a long-double two-loop on 40 hill problems (history up to 237 pairs): max relative error 4e-14, the
-    // double two-loop's own is 1e-13.  NG = ceil(b / 64) register groups hold the b-vectors of wave 0.
-#if UPH_COMPACT_DIRECTION
-    template <int NG>
-    __device__ __forceinline__ void directionT(double* d, const double* g, const double* ynew, int n_, const double* S_, const double* Y_, const double* St_,
-                                               const double* Yt_, double* SY_, double* YS_, double* YY_, const double* ysTab_, double* sc, double* dg_out,
-                                               int m_, int end_, int bound_, double gamma_) {
-        typedef __attribute__((address_space(1))) double* gptr;
-        const int n = uni(n_), m = uni(m_), end = uni(end_), b = uni(bound_);
-        const double gamma = uni(gamma_);
-        const int start = end - b < 0 ? end - b + m : end - b;          // ring slot of age 0
-        const int e = end == 0 ? m - 1 : end - 1;                       // ring slot of the newest pair (age b-1)
-        const gcptr S = uniG(S_), Y = uniG(Y_), St = uniG(St_), Yt = uniG(Yt_), ysTab = uniG(ysTab_);
-        const gptr SY = (gptr)uniG(SY_), YS = (gptr)uniG(YS_), YY = (gptr)uniG(YY_);
-        constexpr int NGB = NG * 64;
-        int sl[NG];
-        bool act[NG];
+    // MINCO knot solve: block-tridiagonal sweeps with the precomputed 2x2 block-LU factors (minco_op_host.hpp; table in LDS).
+    //     y_j = P_j r_j - M1_j y_{j-1}  (j ascending),      z_j = Q_j y_j - M2_j z_{j+1}  (j descending),   in place on LDS buffers.
+    // The recurrence is serial in j, so it runs "systolically" across the lanes of one wave: lane l owns knots 2l+1 and 2l+2 with
+    // their right-hand sides and factors in registers, every step hands the lane's last value to its neighbour with one
+    // whole-wave DPP shift (no LDS, no memory access inside the loop) and all lanes recompute; after s steps the first s lanes hold
+    // their final values, so ceil(len / 2) steps complete a sweep.  Knots beyond the chain carry all-zero factors (they produce
+    // zeros, which is exactly what the last real knot must see).  The x and y chains share one wave (lanes 0-31 / 32-63): M1 of
+    // every chain's first knot is zero, so lane 32 ignores what lane 31 hands over.  Wave 0 takes the yaw chain, wave 1 (if there
+    // is one) the x / y chains concurrently.
+    static __device__ __forceinline__ double shr1(double v) {   // lane l <- lane l-1, lane 0 <- 0
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+        return __hiloint2double(hi, lo);
+    }
+    static __device__ __forceinline__ double shl1(double v) {   // lane l <- lane l+1, lane 63 <- 0
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+        return __hiloint2double(hi, lo);
+    }
+    template <bool XY, bool ADJ>
+    __device__ __forceinline__ void thomasWave(const double* tab, double* buf, int len_) {
+        const int len = uni(len_);
+        const int lane = flane();
+        const int hl = XY ? (lane & 31) : lane;
+        const int ja = 2 * hl + 1, jb = ja + 1;                 // knot ids, 1-based
+        const bool va = ja <= len, vb = jb <= len;
+        constexpr int ks = XY ? 4 : 2, cs = XY ? 2 : 1;         // knot / component strides of the buffer
+        double* pa = buf + (size_t)(ja - 1) * ks + (XY ? (lane >> 5) : 0);
+        double* pb = pa + ks;
+        const double ra0 = va ? pa[0] : 0.0, ra1 = va ? pa[cs] : 0.0, rb0 = vb ? pb[0] : 0.0, rb1 = vb ? pb[cs] : 0.0;
+        double Pa[4], M1a[4], Qa[4], M2a[4], Pb[4], M1b[4], Qb[4], M2b[4];
+        thomasFactors<ADJ>(tab, va ? ja : 1, Pa, M1a, Qa, M2a);
+        thomasFactors<ADJ>(tab, vb ? jb : 1, Pb, M1b, Qb, M2b);
 #pragma unroll
-        for (int q = 0; q < NG; q++) {
-            const int a = lane + 64 * q;
-            act[q] = a < b;
-            int s_ = start + (act[q] ? a : b - 1);                      // inactive lanes shadow the newest pair (results ignored)
-            sl[q] = s_ >= m ? s_ - m : s_;
+        for (int k = 0; k < 4; k++) {
+            if (!va) { Pa[k] = 0.0; M1a[k] = 0.0; Qa[k] = 0.0; M2a[k] = 0.0; }
+            if (!vb) { Pb[k] = 0.0; M1b[k] = 0.0; Qb[k] = 0.0; M2b[k] = 0.0; }
         }
-        // ---- 1. lane-per-pair dot products over this wave's share of the elements
-        {
-            const int kc = (n + NW - 1) / NW, k0 = wave * kc, k1 = (k0 + kc < n) ? k0 + kc : n;
-            double acc[NG][4];
-#pragma unroll
-            for (int q = 0; q < NG; q++) { acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.0; }
-            constexpr int U1 = 16 / NG;                                 // 16 x 2 loads in flight per lane whatever NG is
-            int k = k0;
-            for (; k + U1 <= k1; k += U1) {
-                double sv[U1][NG], yv[U1][NG];
-#pragma unroll
-                for (int t = 0; t < U1; t++)
-#pragma unroll
-                    for (int q = 0; q < NG; q++) { sv[t][q] = St[(size_t)(k + t) * m + sl[q]]; yv[t][q] = Yt[(size_t)(k + t) * m + sl[q]]; }
-#pragma unroll
-                for (int t = 0; t < U1; t++) {
-                    const double gk = g[k + t], yk = ynew[k + t];
-#pragma unroll
-                    for (int q = 0; q < NG; q++) {
-                        acc[q][0] += sv[t][q] * gk; acc[q][1] += yv[t][q] * gk; acc[q][2] += sv[t][q] * yk; acc[q][3] += yv[t][q] * yk;
-                    }
-                }
-            }
-            if (k < k1) {                                               // tail: one more batch, indices clamped, products masked
-                double sv[U1][NG], yv[U1][NG];
-#pragma unroll
-                for (int t = 0; t < U1; t++) {
-                    const int kk = k + t < k1 ? k + t : k1 - 1;
-#pragma unroll
-                    for (int q = 0; q < NG; q++) { sv[t][q] = St[(size_t)kk * m + sl[q]]; yv[t][q] = Yt[(size_t)kk * m + sl[q]]; }
-                }
-#pragma unroll
-                for (int t = 0; t < U1; t++) {
-                    const bool on = k + t < k1;
-                    const int kk = on ? k + t : k1 - 1;
-                    const double gk = on ? g[kk] : 0.0, yk = on ? ynew[kk] : 0.0;
-#pragma unroll
-                    for (int q = 0; q < NG; q++) {
-                        acc[q][0] += sv[t][q] * gk; acc[q][1] += yv[t][q] * gk; acc[q][2] += sv[t][q] * yk; acc[q][3] += yv[t][q] * yk;
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NG; q++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) sc[(wave * 4 + c) * NGB + lane + 64 * q] = acc[q][c];
+        double Pa0, Pa1, Pb0, Pb1;
+        mv2(Pa, ra0, ra1, Pa0, Pa1);
+        mv2(Pb, rb0, rb1, Pb0, Pb1);
+        const int steps = (len + 1) >> 1;
+        double ya0 = 0.0, ya1 = 0.0, yb0 = 0.0, yb1 = 0.0;
+        for (int s = 0; s < steps; s++) {
+            const double p0 = shr1(yb0), p1 = shr1(yb1);
+            submv2(Pa0, Pa1, M1a, p0, p1, ya0, ya1);
+            submv2(Pb0, Pb1, M1b, ya0, ya1, yb0, yb1);
         }
-        __syncthreads();
-        double* ca = sc;                     // coefficient arrays for step 3 (reuse the partial-sum area after step 2 consumed it)
-        double* cb = sc + NGB;
-        if (wave == 0) {
-            __builtin_amdgcn_s_setprio(3);
-            double u[NG], v[NG], r[NG], z[NG], ysv[NG], rinv[NG];
-#pragma unroll
-            for (int q = 0; q < NG; q++) {
-                double t4[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    double t = sc[c * NGB + lane + 64 * q];
-#pragma unroll
-                    for (int w = 1; w < NW; w++) t += sc[(w * 4 + c) * NGB + lane + 64 * q];
-                    t4[c] = t;
-                }
-                u[q] = t4[0]; v[q] = t4[1]; r[q] = t4[2]; z[q] = t4[3];
-                ysv[q] = ysTab[2 * sl[q]]; rinv[q] = ysTab[2 * sl[q] + 1];
-            }
-            // Gram entries of the new pair (ring slot e).  SY[i][j] = s_i . y_j is kept ONLY where pair i is older than pair j and is
-            // zero elsewhere (YS is its transpose), so that the triangular solves need no masks: row e of SY and column e of YS are
-            // cleared (whatever pair lived in slot e before is gone, and e is older than nobody), column e of SY / row e of YS take
-            // r_a = s_a . y_new for the older pairs.  YY is symmetric and complete.
-            for (int sl0 = lane; sl0 < m; sl0 += 64) { SY[(size_t)e * m + sl0] = 0.0; YS[(size_t)e * m + sl0] = 0.0; }
-#pragma unroll
-            for (int q = 0; q < NG; q++) {
-                const int a = lane + 64 * q;
-                if (a < b - 1) {
-                    SY[(size_t)sl[q] * m + e] = r[q]; YS[(size_t)e * m + sl[q]] = r[q];
-                    YS[(size_t)sl[q] * m + e] = 0.0;
-                    YY[(size_t)e * m + sl[q]] = z[q]; YY[(size_t)sl[q] * m + e] = z[q];
-                } else if (a == b - 1) {
-                    YY[(size_t)e * m + e] = z[q];
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the solves below re-read entries of column e from memory
-            // Both solves are column-oriented chains of b steps (pivot lane read -> multiply -> masked FMA); the matrix rows they
-            // consume do not depend on the chain, so they stream through a register ring PFD steps ahead with the same fenced,
-            // branch-free steady state as the two-loop (exact vmcnt waits, no register rotation).  All NG groups are loaded at
-            // every step (the age masks zero what lies outside the triangle).
-            constexpr int PFD = 24 / NG;
-            auto selq = [&](const double* x, int qq) {                 // x[qq] for a wave-uniform qq
-                double r_ = x[0];
-#pragma unroll
-                for (int q = 1; q < NG; q++) r_ = qq == q ? x[q] : r_;
-                return r_;
-            };
-            // ---- 2a. back substitution R p = u, newest -> oldest, with tacc += YY[:, j] p_j on the fly
-            double w[NG], tacc[NG], p1[NG];
-#pragma unroll
-            for (int q = 0; q < NG; q++) { w[q] = u[q]; tacc[q] = 0.0; p1[q] = 0.0; }
-            {
-                double Rc[PFD][NG], Yc[PFD][NG];
-                auto fetch = [&](int slot, int j) {
-                    j = j < 0 ? 0 : j;
-                    int sj = start + j; sj = sj >= m ? sj - m : sj;
-#pragma unroll
-                    for (int q = 0; q < NG; q++) { Rc[slot][q] = YS[(size_t)sj * m + sl[q]]; Yc[slot][q] = YY[(size_t)sj * m + sl[q]]; }
-                };
-                auto step = [&](int slot, int j) {
-                    const int qj = j >> 6, l = j & 63;
-                    const double pj = readLane(selq(w, qj) * selq(rinv, qj), l);          // pivot p_j = w_j / R_jj, wave-uniform
-#pragma unroll
-                    for (int q = 0; q < NG; q++) {
-                        if (NG == 1 || q == qj) p1[q] = writeLane(pj, l, p1[q]);
-                        w[q] = fma(-Rc[slot][q], pj, w[q]);                                // (zeros outside the triangle: no mask)
-                        tacc[q] = fma(Yc[slot][q], pj, tacc[q]);
-                    }
-                };
-                auto pin = [&]() {
-#pragma unroll
-                    for (int q = 0; q < NG; q++) { asm volatile("" : "+v"(w[q]) : : "memory"); asm volatile("" : "+v"(tacc[q]) : : "memory"); }
-                };
-#pragma unroll
-                for (int x = 0; x < PFD; x++) fetch(x, b - 1 - x);
-                int i = 0;
-                for (; i + PFD <= b; i += PFD) {
-#pragma unroll
-                    for (int x = 0; x < PFD; x++) {
-                        step(x, b - 1 - (i + x));
-                        pin();
-                        fetch(x, b - 1 - (i + x) - PFD);
-                    }
-                }
-                const int rem = b - i;
-#pragma unroll
-                for (int x = 0; x < PFD - 1; x++) if (x < rem) step(x, b - 1 - (i + x));
-            }
-            // ---- 2b. forward substitution R^T a = (D + gamma Y^T Y) p - gamma v, oldest -> newest
-            double t[NG], ac[NG];
-#pragma unroll
-            for (int q = 0; q < NG; q++) { t[q] = ysv[q] * p1[q] + gamma * (tacc[q] - v[q]); ac[q] = 0.0; }
-            {
-                double Rr[PFD][NG];
-                auto fetch = [&](int slot, int i_) {
-                    i_ = i_ > b - 1 ? b - 1 : i_;
-                    int si = start + i_; si = si >= m ? si - m : si;
-#pragma unroll
-                    for (int q = 0; q < NG; q++) Rr[slot][q] = SY[(size_t)si * m + sl[q]];
-                };
-                auto step = [&](int slot, int i_) {
-                    const int qi = i_ >> 6, l = i_ & 63;
-                    const double ai = readLane(selq(t, qi) * selq(rinv, qi), l);
-#pragma unroll
-                    for (int q = 0; q < NG; q++) {
-                        if (NG == 1 || q == qi) ac[q] = writeLane(ai, l, ac[q]);
-                        t[q] = fma(-Rr[slot][q], ai, t[q]);
-                    }
-                };
-                auto pin = [&]() {
-#pragma unroll
-                    for (int q = 0; q < NG; q++) asm volatile("" : "+v"(t[q]) : : "memory");
-                };
-#pragma unroll
-                for (int x = 0; x < PFD; x++) fetch(x, x);
-                int i = 0;
-                for (; i + PFD <= b; i += PFD) {
-#pragma unroll
-                    for (int x = 0; x < PFD; x++) {
-                        step(x, i + x);
-                        pin();
-                        fetch(x, i + x + PFD);
-                    }
-                }
-                const int rem = b - i;
-#pragma unroll
-                for (int x = 0; x < PFD - 1; x++) if (x < rem) step(x, i + x);
-            }
-#pragma unroll
-            for (int q = 0; q < NG; q++) { ca[lane + 64 * q] = ac[q]; cb[lane + 64 * q] = -gamma * p1[q]; }
-            __builtin_amdgcn_s_setprio(0);
+        double qa0, qa1, qb0, qb1;
+        mv2(Qa, ya0, ya1, qa0, qa1);
+        mv2(Qb, yb0, yb1, qb0, qb1);
+        double za0 = 0.0, za1 = 0.0, zb0 = 0.0, zb1 = 0.0;
+        for (int s = 0; s < steps; s++) {
+            const double p0 = shl1(za0), p1 = shl1(za1);
+            submv2(qb0, qb1, M2b, p0, p1, zb0, zb1);
+            submv2(qa0, qa1, M2a, zb0, zb1, za0, za1);
         }
-        __syncthreads();
-        // ---- 3. d = -(gamma g + S a - gamma Y p): one lane per element, pairs in age order
-        for (int k = tid; k < n; k += NT) {
-            double acc = gamma * g[k];
-            int sa = start;
-            int a = 0;
-            for (; a < b; a += 16) {                                    // 32 loads in flight; the last batch clamps its pair index and masks
-                double sv[16], yv[16];
-#pragma unroll
-                for (int t = 0; t < 16; t++) {
-                    int s_ = sa + (a + t < b ? t : b - 1 - a); s_ = s_ >= m ? s_ - m : s_;
-                    sv[t] = S[(size_t)s_ * n + k]; yv[t] = Y[(size_t)s_ * n + k];
-                }
-#pragma unroll
-                for (int t = 0; t < 16; t++) {
-                    const bool on = a + t < b;
-                    const int at = on ? a + t : b - 1;
-                    acc += on ? sv[t] * ca[at] + yv[t] * cb[at] : 0.0;
-                }
-                sa += 16; sa = sa >= m ? sa - m : sa;
-            }
-            d[k] = -acc;
+        if (va) { pa[0] = za0; pa[cs] = za1; }
+        if (vb) { pb[0] = zb0; pb[cs] = zb1; }
+    }
+    template <bool ADJ>
+    __device__ __forceinline__ void thomasT(const double* tab, double* bw, int lenW, double* bx, int lenX) {
+        __builtin_amdgcn_s_setprio(3);              // dependency chains: let them win the issue arbitration
+        if (NW >= 2) {
+            if (wave == 0) thomasWave<false, ADJ>(tab, bw, lenW);
+            else if (wave == 1) thomasWave<true, ADJ>(tab, bx, lenX);
+        } else {
+            thomasWave<false, ADJ>(tab, bw, lenW);
+            thomasWave<true, ADJ>(tab, bx, lenX);
         }
-        double gd[1];
-        sum<1>(n, gd, [&](int k, double* ac1) { ac1[0] += g[k] * d[k]; });
-        if (tid == 0) *dg_out = gd[0];
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
-#endif
-    __device__ __forceinline__ void direction(double* d, const double* g, const double* ynew, int n, const double* S, const double* Y, const double* St, const double* Yt,
-                                              double* SY, double* YS, double* YY, const double* ysTab, double* sc, double* dg_out, int m, int end, int bound, double gamma) {
-#if !UPH_COMPACT_DIRECTION
-        __builtin_trap();       // not compiled in (the host never sets BatchDev::compact in this build)
-#else
-        const int ng = uni((bound + 63) >> 6);
-        if (ng <= 1) directionT<1>(d, g, ynew, n, S, Y, St, Yt, SY, YS, YY, ysTab, sc, dg_out, m, end, bound, gamma);
-        else if (ng == 2) directionT<2>(d, g, ynew, n, S, Y, St, Yt, SY, YS, YY, ysTab, sc, dg_out, m, end, bound, gamma);
-        else if (ng == 3) directionT<3>(d, g, ynew, n, S, Y, St, Yt, SY, YS, YY, ysTab, sc, dg_out, m, end, bound, gamma);
-        else directionT<4>(d, g, ynew, n, S, Y, St, Yt, SY, YS, YY, ysTab, sc, dg_out, m, end, bound, gamma);
-#endif
+    __device__ __forceinline__ void thomas(const double* tab, bool adj, double* bw, int lenW, double* bx, int lenX) {
+        if (adj) thomasT<true>(tab, bw, lenW, bx, lenX);
+        else thomasT<false>(tab, bw, lenW, bx, lenX);
     }
     __device__ __forceinline__ void twoLoop(double* d, const double* g, int n, const double* __restrict__ lm_s, const double* __restrict__ lm_y,
                                             const double* __restrict__ lm_ys, double* dg_out, double* al_lds, int m, int end, int bound, double scale) {
@@ -546,7 +372,7 @@ struct DevWG {
     template <class F>
     __device__ __forceinline__ double maxv(int n, F f) {
         double a = 0.0;
-        for (int i = tid; i < n; i += NT) { const double v = f(i); a = v > a ? v : a; }
+        for (int i = ftid(); i < n; i += NT) { const double v = f(i); a = v > a ? v : a; }
         a = waveMax(a);
         double* r = red + par * (NW * MAXM);
         par ^= 1;
@@ -640,8 +466,7 @@ struct uph_ctx {
     int lanes_forced = 0;                   // 0 = choose from the batch size
     int wps = 1;                            // workgroups of 256 lanes per CU the kernel is compiled for (1 or 2)
     int wps_forced = 0;                     // experiment knob: register-capped (2) or uncapped (1) build regardless of batch size
-    DevBuf d_lmys, d_xpgp, d_lmst, d_lmyt, d_gram;
-    int compact = 1;                        // L-BFGS direction: 1 compact form (default), 0 two-loop recursion (UPH_TWOLOOP=1 or uph_ctx_set_direction)
+    DevBuf d_lmys, d_thomas;
     DevBuf d_desc, d_state, d_x, d_x0, d_gout, d_dual, d_res, d_scl, d_cxy, d_cyaw, d_lms, d_lmy, d_report, d_order, d_trace;
     int trace_cap = 0;
     std::vector<TrajState> state_host;
@@ -670,17 +495,12 @@ static BatchDev makeBatchDev(uph_ctx* c) {
     bd.dual = c->d_dual.as<double>(); bd.res = c->d_res.as<double>(); bd.scl = c->d_scl.as<double>();
     bd.cxy = c->d_cxy.as<double>(); bd.cyaw = c->d_cyaw.as<double>();
     bd.lm_s = c->d_lms.as<double>(); bd.lm_y = c->d_lmy.as<double>();
-    bd.lm_ys = c->d_lmys.as<double>(); bd.xpgp = c->d_xpgp.as<double>();
-    bd.lm_st = c->d_lmst.as<double>(); bd.lm_yt = c->d_lmyt.as<double>();
-    {
-        const size_t mm = (size_t)c->P.mem_size * c->P.mem_size * (size_t)(c->B > 0 ? c->B : 0);
-        bd.lm_sy = c->d_gram.as<double>(); bd.lm_ysT = bd.lm_sy ? bd.lm_sy + mm : nullptr; bd.lm_yy = bd.lm_sy ? bd.lm_sy + 2 * mm : nullptr;
-    }
-    bd.compact = c->compact && bd.lm_sy != nullptr;
+    bd.lm_ys = c->d_lmys.as<double>();
     bd.report = c->d_report.as<double>();
     bd.trace = c->trace_cap > 0 ? c->d_trace.as<double>() : nullptr;
     bd.trace_cap = c->trace_cap;
     bd.order = c->d_order.as<int>();
+    bd.thomas = c->d_thomas.as<double>();
     return bd;
 }
 
@@ -784,8 +604,13 @@ int uph_ctx_create(uph_map* m, const uph_opt_params* p, uph_ctx** out) {
     // lbfgs.hpp:76-128 defaults, not overridden at alm_traj_opt.cpp:219-225
     P.max_linesearch = 64; P.max_step = 1.0e20; P.f_dec_coeff = 1.0e-4; P.s_curv_coeff = 0.9; P.cautious_factor = 1.0e-6; P.machine_prec = 1.0e-16;
     finishParams(P);
-    c->compact = (!UPH_COMPACT_DIRECTION || getenv("UPH_TWOLOOP") || P.mem_size > 256) ? 0 : 1;      // the compact form keeps its vectors in 4 x 64 lane registers
     c->rho = p->rho;
+    {
+        std::vector<double> tab;
+        buildThomasTable(tab);
+        if (c->d_thomas.ensure(tab.size() * sizeof(double))) { delete c; return UPH_ERR_HIP; }
+        if (hipMemcpy(c->d_thomas.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { setError("hipMemcpy(thomas table) failed"); c->d_thomas.release(); delete c; return UPH_ERR_HIP; }
+    }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev2));
@@ -800,7 +625,7 @@ void uph_ctx_destroy(uph_ctx* c) {
     hipSetDevice(c->device);             // not via c->map: the map may already have been destroyed by the caller
     for (void* p : c->op_allocs) hipFree(p);
     DevBuf* bufs[] = {&c->d_ops, &c->d_desc, &c->d_state, &c->d_x, &c->d_gout, &c->d_dual, &c->d_res, &c->d_scl, &c->d_cxy, &c->d_cyaw,
-                      &c->d_lms, &c->d_lmy, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_lmys, &c->d_xpgp, &c->d_lmst, &c->d_lmyt, &c->d_gram};
+                      &c->d_lms, &c->d_lmy, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_lmys, &c->d_thomas};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -817,13 +642,6 @@ int uph_ctx_set_lanes(uph_ctx* c, int32_t lanes) {
     return UPH_OK;
 }
 int uph_ctx_set_wps(uph_ctx* c, int32_t wps) { if (!c || wps < 0 || wps > 2) return UPH_ERR_INVALID; c->wps_forced = wps; return UPH_OK; }
-// L-BFGS direction: 1 = compact representation (parallel; default), 0 = two-loop recursion in the reference's order of operations
-int uph_ctx_set_direction(uph_ctx* c, int32_t compact) {
-    if (!c || (compact != 0 && compact != 1)) return UPH_ERR_INVALID;
-    if (compact && !UPH_COMPACT_DIRECTION) { setError("uph_ctx_set_direction: this build has no compact direction (compile with -DUPH_COMPACT_DIRECTION=1)"); return UPH_ERR_INVALID; }
-    c->compact = compact;
-    return UPH_OK;
-}
 int uph_ctx_set_rho(uph_ctx* c, double rho) { if (!c) return UPH_ERR_INVALID; c->rho = rho; return UPH_OK; }
 int uph_ctx_get_rho(uph_ctx* c, double* rho) { if (!c || !rho) return UPH_ERR_INVALID; *rho = c->rho; return UPH_OK; }
 
@@ -880,8 +698,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     }
     if (c->d_desc.ensure(sizeof(TrajDesc) * B) || c->d_state.ensure(sizeof(TrajState) * B) || c->d_x.ensure(8 * on) || c->d_x0.ensure(8 * on) || c->d_gout.ensure(8 * on) ||
         c->d_dual.ensure(8 * 7 * os) || c->d_res.ensure(8 * 7 * os) || c->d_scl.ensure(8 * 7 * os) || c->d_cxy.ensure(8 * ocx) || c->d_cyaw.ensure(8 * ocy) ||
-        c->d_lms.ensure(8 * oh) || c->d_lmy.ensure(8 * oh) || c->d_lmys.ensure(16 * (size_t)mem * B) || c->d_xpgp.ensure(16 * on) ||
-        (c->compact && (c->d_lmst.ensure(8 * oh) || c->d_lmyt.ensure(8 * oh) || c->d_gram.ensure(3 * 8 * (size_t)mem * mem * B))) || c->d_report.ensure(8 * 7 * B) || c->d_order.ensure(4 * B) ||
+        c->d_lms.ensure(8 * oh) || c->d_lmy.ensure(8 * oh) || c->d_lmys.ensure(16 * (size_t)mem * B) || c->d_report.ensure(8 * 7 * B) || c->d_order.ensure(4 * B) ||
         c->d_trace.ensure(8 * (size_t)std::max(1, c->trace_cap) * B))
         return UPH_ERR_HIP;
     // x0 = [tau | Pxy | Pyaw]  (alm_traj_opt.cpp:206-216)
@@ -987,7 +804,7 @@ int uph_batch_prepare_ms(uph_ctx* c, double* ms) { if (!c || !ms) return UPH_ERR
 // diagnostic: per-trajectory phase cycle counters of the last solve, out[B][8] (see TrajState::cyc)
 int uph_batch_cycles(uph_ctx* c, long long* out) {
     if (!c || c->B <= 0 || !out) return UPH_ERR_INVALID;
-    for (int b = 0; b < c->B; b++) for (int q = 0; q < 8; q++) out[b * 8 + q] = c->state_host[b].cyc[q];
+    for (int b = 0; b < c->B; b++) for (int q = 0; q < 16; q++) out[b * 16 + q] = c->state_host[b].cyc[q];
     return UPH_OK;
 }
 

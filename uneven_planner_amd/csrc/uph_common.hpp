@@ -24,12 +24,6 @@
 #define UPH_AS_GLOBAL(p) (p)
 #endif
 
-// The compact (Byrd-Nocedal-Schnabel) L-BFGS direction is an experimental build option (see unevenhip.hip):
-// -DUPH_COMPACT_DIRECTION=1 compiles it in; the CPU emulator of the test-suite always does.
-#ifndef UPH_COMPACT_DIRECTION
-#define UPH_COMPACT_DIRECTION 0
-#endif
-
 namespace uph {
 
 constexpr int MAX_PIECE_XY = 64;
@@ -131,7 +125,7 @@ struct TrajState {
     double f, jerk_cost, T_xy, T_yaw;
     int ret_code, alm_iters, lbfgs_iters, evals, last_lbfgs_ret, pad;
     long long hist_reads;       // doubles read from the L-BFGS history (two-loop), for the roofline accounting
-    long long cyc[8];           // shader-clock cycles per phase: 0 generate, 1 samples, 2 scatter, 3 adjoint, 4 two-loop, 5 scaling, 6 total
+    long long cyc[16];          // shader-clock cycles per phase: 0 generate, 1 samples, 2 scatter, 3 adjoint, 4 two-loop, 5 scaling, 6 total; 8.. sub-steps (microbench)
 };
 
 struct BatchDev {
@@ -150,18 +144,11 @@ struct BatchDev {
     double* lm_s;       // [sum mem*n]
     double* lm_y;
     double* lm_ys;      // [B*2*mem]  per trajectory: (y_j . s_j, 1 / (y_j . s_j)) of every stored pair, interleaved (read by the two-loop)
-    // compact (Byrd-Nocedal-Schnabel) L-BFGS direction: transposed history and the Gram matrices by physical ring slot
-    double* lm_st;      // [sum n*mem]  S transposed: element k of pair slot j at k*mem + j (lane-per-pair dot products)
-    double* lm_yt;      // [sum n*mem]  Y transposed
-    double* lm_sy;      // [B*mem*mem]  SY[i][j] = s_i . y_j   (rows of R for the forward substitution)
-    double* lm_ysT;     // [B*mem*mem]  its transpose          (columns of R for the back substitution)
-    double* lm_yy;      // [B*mem*mem]  YY[i][j] = y_i . y_j (symmetric)
-    int compact;        // 1: compact direction, 0: two-loop recursion (reference order of operations)
-    double* xpgp;       // [2*sum n] previous iterate and gradient of the L-BFGS line search (xp | gp per trajectory)
     double* report;     // [B*7]
     double* trace;      // optional [B*trace_cap] diagnostic cost trace (nullptr = off)
     int trace_cap;
     const int* order;   // optional launch order: workgroup w solves trajectory order[w] (longest first)
+    const double* thomas;   // block-LU factors of the MINCO knot system, THOMAS_DOUBLES (minco_op_host.hpp); shared by every trajectory, copied to LDS per workgroup
 };
 
 UPH_HD double dmax(double a, double b) { return a > b ? a : b; }
@@ -174,6 +161,84 @@ UPH_HD double expC2(double tau) { return tau > 0.0 ? ((0.5 * tau + 1.0) * tau + 
 UPH_HD double divR(double x, double y, double r) {
     const double q0 = x * r;
     return fma(fma(-q0, y, x), r, q0);
+}
+// 2x2 block helpers of the MINCO knot sweeps (M row-major).  Explicit fma so that the device and the CPU emulator round alike.
+UPH_HD void mv2(const double* M, double v0, double v1, double& o0, double& o1) {
+    o0 = fma(M[1], v1, M[0] * v0);
+    o1 = fma(M[3], v1, M[2] * v0);
+}
+UPH_HD void submv2(double r0, double r1, const double* M, double p0, double p1, double& o0, double& o1) {   // r - M p
+    o0 = fma(-M[1], p1, fma(-M[0], p0, r0));
+    o1 = fma(-M[3], p1, fma(-M[2], p0, r1));
+}
+// Block-LU factors of the MINCO knot system (minco_op_host.hpp): table entry j = {L_j, D_j^-1}, constant from j = THOMAS_J on.
+constexpr int THOMAS_J = 26;
+constexpr int THOMAS_STRIDE = 8;
+constexpr int THOMAS_DOUBLES = (THOMAS_J + 1) * THOMAS_STRIDE;
+// the four 2x2 matrices of knot j for the forward (M z = r) or adjoint (M^T lambda = g) sweeps, C = [8 -1; -7 1]
+template <bool ADJ>
+UPH_HD void thomasFactors(const double* tab, int j, double* P, double* M1, double* Q, double* M2) {
+    const double* e = tab + (j < THOMAS_J ? j : THOMAS_J) * THOMAS_STRIDE;
+    const double* en = tab + (j + 1 < THOMAS_J ? j + 1 : THOMAS_J) * THOMAS_STRIDE;
+    const double D00 = e[4], D01 = e[5], D10 = e[6], D11 = e[7];
+    if (!ADJ) {
+        P[0] = 1.0; P[1] = 0.0; P[2] = 0.0; P[3] = 1.0;
+        M1[0] = e[0]; M1[1] = e[1]; M1[2] = e[2]; M1[3] = e[3];                 // L_j (zero at j = 1)
+        Q[0] = D00; Q[1] = D01; Q[2] = D10; Q[3] = D11;
+        M2[0] = fma(8.0, D00, -7.0 * D01); M2[1] = D01 - D00; M2[2] = fma(8.0, D10, -7.0 * D11); M2[3] = D11 - D10;   // D^-1 C
+    } else {
+        P[0] = D00; P[1] = D10; P[2] = D01; P[3] = D11;                         // D^-T
+        const double z = j == 1 ? 0.0 : 1.0;                                    // a chain's first knot has no predecessor
+        M1[0] = z * fma(8.0, D00, -D10); M1[1] = z * fma(-7.0, D00, D10); M1[2] = z * fma(8.0, D01, -D11); M1[3] = z * fma(-7.0, D01, D11);   // (C D^-1)^T
+        Q[0] = 1.0; Q[1] = 0.0; Q[2] = 0.0; Q[3] = 1.0;
+        M2[0] = en[0]; M2[1] = en[2]; M2[2] = en[1]; M2[3] = en[3];             // L_{j+1}^T
+    }
+}
+// sin and cos of one argument, < 0.8 ulp each (measured against long double on 1.4e7 arguments up to 1e9).  Why not the device
+// library's sincos: its polynomial constants are loop-invariant 64-bit literals, the compiler hoists their materialisation out
+// of the solver's loops into VGPRs and -- at the register cap of the solve kernel -- spills them to scratch, so that every
+// sample paid nine serialised scratch reloads inside the Horner chain.  Here the coefficients come from a small constant-memory
+// table through an opaque pointer: scalar loads issued at the call, nothing to hoist, no vector registers held.
+// Reduction: q = rint(x 2/pi); r + rt = x - q pi/2 with pi/2 = P1 + P2 + P3 (every product exact inside its fma, the roundings
+// of the two subtractions recovered into the tail rt); kernels: fdlibm's __kernel_sin / __kernel_cos with tail.
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __constant__ const double UPH_SINCOS_TAB[16] = {
+#else
+static const double UPH_SINCOS_TAB[16] = {
+#endif
+    0x1.45f306dc9c883p-1,                                                    // 0  2/pi
+    0x1.921fb54442d18p+0, 0x1.1a62633145c07p-54, -0x1.f1976b7ed8fbcp-110,    // 1-3  pi/2 in three parts
+    -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,     // 4-9  S1..S6
+    2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+    4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,      // 10-15  C1..C6
+    -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11};
+UPH_HD void sincosFast(double x, double& sn, double& cs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) double* ctab_t;
+    ctab_t T = (ctab_t)UPH_SINCOS_TAB;
+    asm volatile("" : "+s"(T));
+#else
+    const double* T = UPH_SINCOS_TAB;
+#endif
+    const double q = rint(x * T[0]);
+    const double t = fma(-q, T[1], x);
+    const double w = q * T[2];
+    const double r = t - w;
+    double rt = (t - r) - w;
+    rt = fma(-q, T[2], w) + rt;
+    rt = fma(-q, T[3], rt);
+    const double z = r * r;
+    const double v = z * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, T[9], T[8]), T[7]), T[6]), T[5]);
+    const double sr = r - ((z * (0.5 * rt - v * ps) - rt) - v * T[4]);
+    const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, T[15], T[14]), T[13]), T[12]), T[11]), T[10]);
+    const double hz = 0.5 * z;
+    const double w1 = 1.0 - hz;
+    const double cr = w1 + (((1.0 - w1) - hz) + (z * pc - r * rt));
+    const int n = (int)((long long)q & 3);       // |x| < 2^62 / (2/pi); beyond that the argument carries no angle information
+    const double s0 = (n & 1) ? cr : sr, c0 = (n & 1) ? sr : cr;
+    sn = (n & 2) ? -s0 : s0;
+    cs = (n == 1 || n == 2) ? -c0 : c0;
 }
 UPH_HD double logC2(double T) { return T > 1.0 ? (sqrt(2.0 * T - 1.0) - 1.0) : (1.0 - sqrt(2.0 / T - 1.0)); }
 UPH_HD double getTtoTauGrad(double tau) {
