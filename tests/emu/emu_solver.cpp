@@ -66,30 +66,33 @@ struct HostWG {
         }
         for (int m = 0; m < MM; m++) { double v = 0.0; for (int t = 0; t < L; t++) v = pm[t][m] > v ? pm[t][m] : v; outM[m] = v; }
     }
-    void twoLoop(double* d, const double* g, int n, const double* lm_s, const double* lm_y, const double* lm_ys, double* dg_out, double* /*al_lds*/, int m, int end, int bound, double scale) {
+    void twoLoop(double* d, const double* g, int n, const double* hist, double* dg_out, double* /*al_lds*/, int m, int end, int bound, double scale) {
         double lm_alpha[512];
+        const int rowd = histRowDoubles(n), np = 64 * histNQ(n);
         int j = end;
         for (int i = 0; i < bound; ++i) {
             j = (j + m - 1) % m;
-            const double* sj = lm_s + (size_t)j * n;
-            const double* yj = lm_y + (size_t)j * n;
+            const double* row = hist + (size_t)j * rowd;
+            const double* sj = row + 2;
+            const double* yj = row + 2 + np;
             double part[64] = {0};
             for (int t = 0; t < n; t++) part[t & 63] += sj[t] * d[t];
             double tot = 0.0;
             for (int l = 0; l < 64; l++) tot += part[l];
-            const double al = tot / lm_ys[2 * j];
+            const double al = tot / row[0];
             lm_alpha[j] = al;
             for (int t = 0; t < n; t++) d[t] += (-al) * yj[t];
         }
         for (int t = 0; t < n; t++) d[t] *= scale;
         for (int i = 0; i < bound; ++i) {
-            const double* sj = lm_s + (size_t)j * n;
-            const double* yj = lm_y + (size_t)j * n;
+            const double* row = hist + (size_t)j * rowd;
+            const double* sj = row + 2;
+            const double* yj = row + 2 + np;
             double part[64] = {0};
             for (int t = 0; t < n; t++) part[t & 63] += yj[t] * d[t];
             double tot = 0.0;
             for (int l = 0; l < 64; l++) tot += part[l];
-            const double beta = tot / lm_ys[2 * j];
+            const double beta = tot / row[0];
             const double a = lm_alpha[j] - beta;
             for (int t = 0; t < n; t++) d[t] += a * sj[t];
             j = (j + 1) % m;
@@ -206,7 +209,7 @@ void emu_run(void* h, int mode, int n_inner_xy, int n_inner_yaw, const double* i
     std::memset(&st, 0, sizeof(st));
     st.rho = scal[0]; st.scale_fx = scal[1];
     std::vector<double> dual(7 * S), res(7 * S, 0.0), scl(7 * S), xg(x_io, x_io + n), gout(n, 0.0), cxy(12 * td.Nxy), cyaw(6 * td.Nyaw);
-    std::vector<double> lms((size_t)e->P.mem_size * n), lmy((size_t)e->P.mem_size * n), rep(7, 0.0), lmys(2 * (size_t)e->P.mem_size, 0.0);
+    std::vector<double> hist((size_t)e->P.mem_size * histRowDoubles(n), 0.0), rep(7, 0.0);
     g_trace.assign(20000, 0.0);
     for (int s = 0; s < S; s++) {
         dual[s] = lambda_io[s];
@@ -216,7 +219,7 @@ void emu_run(void* h, int mode, int n_inner_xy, int n_inner_yaw, const double* i
     BatchDev bd;
     std::memset(&bd, 0, sizeof(bd));
     bd.B = 1; bd.desc = &td; bd.state = &st; bd.ops = ops; bd.x = xg.data(); std::vector<double> x0copy(xg); bd.x0 = x0copy.data(); bd.gout = gout.data(); bd.dual = dual.data(); bd.res = res.data();
-    bd.scl = scl.data(); bd.cxy = cxy.data(); bd.cyaw = cyaw.data(); bd.lm_s = lms.data(); bd.lm_y = lmy.data(); bd.lm_ys = lmys.data(); std::vector<double> thomasTab; buildThomasTable(thomasTab); bd.thomas = thomasTab.data(); bd.report = rep.data(); bd.trace = g_trace.data(); bd.trace_cap = (int)g_trace.size();
+    bd.scl = scl.data(); bd.cxy = cxy.data(); bd.cyaw = cyaw.data(); bd.hist = hist.data(); std::vector<double> thomasTab; buildThomasTable(thomasTab); bd.thomas = thomasTab.data(); bd.report = rep.data(); bd.trace = g_trace.data(); bd.trace_cap = (int)g_trace.size();
     std::vector<double> lds(Solver<HostWG>::ldsDoubles(td.Nxy, td.Nyaw, n, g_lanes, e->P.mem_size, e->P.int_K) + 64);
     HostWG wg;
     Solver<HostWG> sol(wg, e->grid, e->P, bd, 0, lds.data());

@@ -51,9 +51,10 @@ struct Solver {
     int Nxy, Nyaw, n, S, K, mem, CH, CHP, recd;
     // workgroup-shared arrays (LDS)
     int* rtag;
-    double *x, *xp, *g, *gp, *d, *cxy, *cyaw, *Gxy, *Gyaw, *gamxy, *gamyaw, *bt, *rec, *wtab, *ttab, *lm_ys, *pf, *hd;
+    double *x, *xp, *g, *gp, *d, *cxy, *cyaw, *Gxy, *Gyaw, *gamxy, *gamyaw, *bt, *rec, *wtab, *ttab, *pf, *hd;
     // HBM
-    double *dual, *res, *scl, *lm_s, *lm_y;
+    double *dual, *res, *scl, *hist;
+    int hrow, hnp;       // history row length and padded vector length in doubles (uph_common.hpp histRowDoubles)
     const double *Wr_xy, *Wr_yaw;                       // dense knot operators [row][col] (initScaling's row gathers)
     // uniform scalars (identical in every lane)
     double rho, scale_fx, Txy, Tyaw, last_jerk;
@@ -107,11 +108,10 @@ struct Solver {
         rtag = (int*)(rec + (size_t)REC_FIELDS * CHP);
         wtab = q; q += 18 * (K + 1);                         // basis weights of the K + 1 in-piece sample times: [j][k][beta0, beta1, beta2]
         ttab = q; q += THOMAS_DOUBLES;                       // block-LU factors of the knot system
-        lm_ys = bd.lm_ys + (size_t)bidx * 2 * mem;           // pair curvatures and their reciprocals, in HBM
         pf = q; q += MAX_PAST + 8;
         hd = q; q += 18;                                     // head / tail states {P,V,A}: init_xy[6], end_xy[6], init_yaw[3], end_yaw[3]
         dual = bd.dual + 7 * td.off_s; res = bd.res + 7 * td.off_s; scl = bd.scl + 7 * td.off_s;
-        lm_s = bd.lm_s + td.off_hist; lm_y = bd.lm_y + td.off_hist;
+        hist = bd.hist + td.off_hist; hrow = histRowDoubles(n); hnp = 64 * histNQ(n);
         Wr_xy = bd.ops[td.op_xy].Wr; Wr_yaw = bd.ops[td.op_yaw].Wr;
         rho = 0; scale_fx = 1.0; Txy = Tyaw = 0; last_jerk = 0; hist_reads = 0; evals = 0; trace_n = 0;
         for (int q = 0; q < 16; q++) cyc[q] = 0;
@@ -202,7 +202,7 @@ struct Solver {
     // out[0] = energy_xy + energy_yaw, out[1] = sum_i gdT_xy(i), out[2] = sum_i gdT_yaw(i)   (unscaled)
     UPH_HD void expand(const double* xin, double jerk_w, double out[3]) {
         const long long t0 = wg.clock();
-        const double Tx = Txy, Ty = Tyaw, itx = 1.0 / Tx, ity = 1.0 / Ty;
+        const double Tx = Txy, Ty = Tyaw, itx = wg.bcast(1.0 / Tx), ity = wg.bcast(1.0 / Ty);
         const double* zxy = rec;
         const double* zyaw = rec + 4 * (Nxy + 1);
         const int np = 2 * Nxy + Nyaw;
@@ -239,7 +239,8 @@ struct Solver {
             const double d33 = c3 * c3, d43 = c4 * c3, d44 = c4 * c4, d53 = c5 * c3, d54 = c5 * c4, d55 = c5 * c5;
             acc[0] += 36.0 * d33 * T1 + 144.0 * d43 * T2 + 192.0 * d44 * T3 + 240.0 * d53 * T3 + 720.0 * d54 * T4 + 720.0 * d55 * T5;
             const double gT = 36.0 * d33 + 288.0 * d43 * T1 + 576.0 * d44 * T2 + 720.0 * d53 * T2 + 2880.0 * d54 * T3 + 3600.0 * d55 * T4;
-            if (isxy) acc[1] += gT; else acc[2] += gT;
+            acc[1] += isxy ? gT : 0.0;          // (selects, not `acc[isxy ? 1 : 2]`: a dynamically indexed accumulator array would live in scratch)
+            acc[2] += isxy ? 0.0 : gT;
         });
         if (sub_t) sub_t[2] += wg.clock() - t0;
     }
@@ -358,17 +359,38 @@ struct Solver {
         }
     }
 
-    // one constraint sample of calConstrainCostGrad (alm_traj_opt.cpp:716-988).  acc[0] += cost, acc[1] += gdTxy part, acc[2] += gdTyaw part
+    // one constraint sample of calConstrainCostGrad (alm_traj_opt.cpp:716-988).  acc[0] += cost, acc[1] += gdTxy part, acc[2] += gdTyaw part.
+    // The residuals hx / gx (alm_traj_opt.cpp:835, 846 ...) are consumed only by the dual update after an L-BFGS pass, so the
+    // evaluations of the pass do not store them (7 stores per sample and their drain at the chunk barrier): RES_ONLY = true is the
+    // same code up to the residuals, run once over the last evaluated trajectory when the pass ends (refreshResiduals).
+    template <bool RES_ONLY>
     UPH_HD void sampleEval(int s, int slot, double* acc) {
         const int i = divSmall(s, K + 1, inv_k1), j = s - i * (K + 1);
-        // all 14 dual / scale operands are fetched up front: they are independent of the kinematics and of the residual stores
-        // below, but the compiler may not move a load across a store it cannot prove disjoint -- issued here, their HBM/L2
-        // latency overlaps the polynomial evaluation and the terrain gather instead of serialising seven round trips
+        // all 14 dual / scale operands are fetched up front: they are independent of the kinematics, their HBM/L2 latency overlaps
+        // the polynomial evaluation and the terrain gather instead of serialising round trips
         double dl[7], sc7[7];
 #pragma unroll
-        for (int q = 0; q < 7; q++) { dl[q] = dual[q * S + s]; sc7[q] = scl[q * S + s]; }
+        for (int q = 0; q < 7; q++) { dl[q] = RES_ONLY ? 0.0 : dual[q * S + s]; sc7[q] = scl[q * S + s]; }
         Kin k;
         kin<false>(i, j, k);
+        const double icvx = k.tv[0], icvy = k.tv[2], cos_xi = k.tv[4], icxi = k.tv[5], sigma = k.tv[6];
+        const double vx = k.vx, wz = k.wz, ax = k.ax, ay = k.ay, curv = k.curv_snorm;
+        const double nh0 = k.syaw, nh1 = -k.cyaw;
+        // residuals: non-holonomic :830-835, then g1..g6 :841-946 (Q6: without use_scaling only curvature and sigma take fixed scales)
+        const double h = (k.vel[0] * nh0 + k.vel[1] * nh1) * sc7[0];
+        const double g1 = (vx * vx - P.max_vel2) * sc7[1];
+        const double g2 = (ax * ax - P.max_acc_lon2) * sc7[2];
+        const double g3 = (ay * ay - P.max_acc_lat2) * sc7[3];
+        const double sc4 = P.use_scaling ? sc7[4] : cur_scale;
+        const double g4 = (curv - P.max_kap2) * sc4;
+        const double g5 = (P.min_cxi - cos_xi) * sc7[5];
+        const double sc6 = P.use_scaling ? sc7[6] : sig_scale;
+        const double g6 = (sigma - P.max_sig) * sc6;
+        if (RES_ONLY) {
+            res[0 * S + s] = h; res[1 * S + s] = g1; res[2 * S + s] = g2; res[3 * S + s] = g3;
+            res[4 * S + s] = g4; res[5 * S + s] = g5; res[6 * S + s] = g6;
+            return;
+        }
         const double alpha = ec_invK * j;                               // :718  (1.0 / K * j)
         const double gravity = grid.gravity;
         double grad_p[2] = {0, 0}, grad_v[2] = {0, 0}, grad_a[2] = {0, 0};
@@ -379,8 +401,6 @@ struct Solver {
         double W[7] = {0, 0, 0, 0, 0, 0, 0};
         double aug_grad, cost = 0.0;
         const double irho = ec_irho;
-        const double icvx = k.tv[0], icvy = k.tv[2], cos_xi = k.tv[4], icxi = k.tv[5], sigma = k.tv[6];
-        const double vx = k.vx, wz = k.wz, ax = k.ax, ay = k.ay, curv = k.curv_snorm;
         // user-defined cost: surface variation                          :819-827
         const double omega = (j == 0 || j == K) ? ec_omega_h : ec_omega;     // (0.5 *) rho_ter * step * scale_fx
         const double user_cost = omega * sigma * sigma;
@@ -390,9 +410,6 @@ struct Solver {
         // non-holonomic                                                 :829-838
         {
             const double lm = dl[0], sc = sc7[0];
-            const double nh0 = k.syaw, nh1 = -k.cyaw;
-            const double h = (k.vel[0] * nh0 + k.vel[1] * nh1) * sc;
-            res[0 * S + s] = h;
             cost += augCost(h, lm);
             const double ng = augGrad(h, lm) * sc;
             grad_v[0] += ng * nh0; grad_v[1] += ng * nh1;
@@ -400,34 +417,25 @@ struct Solver {
         }
         // longitude velocity                                            :840-854
         {
-            const double mu = dl[1], sc = sc7[1];
-            const double gv = (vx * vx - P.max_vel2) * sc;
-            res[1 * S + s] = gv;
+            const double mu = dl[1], sc = sc7[1], gv = g1;
             if (rho * gv + mu > 0) { cost += augCost(gv, mu); aug_grad = augGrad(gv, mu) * sc; grad_vx2 += aug_grad; }
             else cost += divR(-0.5 * mu * mu, rho, irho);
         }
         // longitude acceleration                                        :856-870
         {
-            const double mu = dl[2], sc = sc7[2];
-            const double gv = (ax * ax - P.max_acc_lon2) * sc;
-            res[2 * S + s] = gv;
+            const double mu = dl[2], sc = sc7[2], gv = g2;
             if (rho * gv + mu > 0) { cost += augCost(gv, mu); aug_grad = augGrad(gv, mu) * sc; grad_ax += aug_grad * 2.0 * ax; }
             else cost += divR(-0.5 * mu * mu, rho, irho);
         }
         // latitude acceleration                                         :872-886
         {
-            const double mu = dl[3], sc = sc7[3];
-            const double gv = (ay * ay - P.max_acc_lat2) * sc;
-            res[3 * S + s] = gv;
+            const double mu = dl[3], sc = sc7[3], gv = g3;
             if (rho * gv + mu > 0) { cost += augCost(gv, mu); aug_grad = augGrad(gv, mu) * sc; grad_ay += aug_grad * 2.0 * ay; }
             else cost += divR(-0.5 * mu * mu, rho, irho);
         }
         // curvature                                                     :888-910  (Q6)
         {
-            const double mu = dl[4];
-            const double sc = P.use_scaling ? sc7[4] : cur_scale;
-            const double gv = (curv - P.max_kap2) * sc;
-            res[4 * S + s] = gv;
+            const double mu = dl[4], sc = sc4, gv = g4;
             if (rho * gv + mu > 0) {
                 const double den = k.den;
                 cost += augCost(gv, mu);
@@ -438,9 +446,7 @@ struct Solver {
         }
         // attitude                                                      :912-925
         {
-            const double mu = dl[5], sc = sc7[5];
-            const double gv = (P.min_cxi - cos_xi) * sc;
-            res[5 * S + s] = gv;
+            const double mu = dl[5], sc = sc7[5], gv = g5;
             if (rho * gv + mu > 0) {
                 cost += augCost(gv, mu);
                 const double ag = augGrad(gv, mu);
@@ -449,10 +455,7 @@ struct Solver {
         }
         // surface variation                                             :927-946  (Q6)
         {
-            const double mu = dl[6];
-            const double sc = P.use_scaling ? sc7[6] : sig_scale;
-            const double gv = (sigma - P.max_sig) * sc;
-            res[6 * S + s] = gv;
+            const double mu = dl[6], sc = sc6, gv = g6;
             if (rho * gv + mu > 0) {
                 cost += augCost(gv, mu);
                 const double ag = augGrad(gv, mu);
@@ -603,7 +606,7 @@ struct Solver {
     // calGradCTtoQT (se2traj.hpp:751-816) through the knot system.  On return gamxy / gamyaw hold gamma = M^T (G T^-k) laid out
     // like beta; chain_xy / chain_yaw = sum_i dW/dT_i without the direct parts (header comment).
     UPH_HD void adjoint(double& chain_xy, double& chain_yaw) {
-        const double Tx = Txy, Ty = Tyaw, itx = 1.0 / Txy, ity = 1.0 / Tyaw;
+        const double Tx = Txy, Ty = Tyaw, itx = wg.bcast(1.0 / Txy), ity = wg.bcast(1.0 / Tyaw);
         const long long ta0 = wg.clock();
         const int nbx = Nxy + 5, nby = Nyaw + 5;
         const int nvec = 2 * nbx + nby;
@@ -627,7 +630,8 @@ struct Solver {
                 const double* cl = c + (size_t)6 * j * os;
                 const double r1 = gl[os], r2 = gl[2 * os], r3 = gl[3 * os], r4 = gl[4 * os], r5 = gl[5 * os];
                 const double chain = -it_ * (cl[os] * r1 + 2.0 * (cl[2 * os] * r2) + 3.0 * (cl[3 * os] * r3) + 4.0 * (cl[4 * os] * r4) + 5.0 * (cl[5 * os] * r5));
-                if (isxy) acc[0] += chain; else acc[1] += chain;
+                acc[0] += isxy ? chain : 0.0;
+                acc[1] += isxy ? 0.0 : chain;
                 const double g0 = gl[0], g1 = r1 * it_, g2 = r2 * i2, g3 = r3 * i3, g4 = r4 * i4, g5 = r5 * i5;
                 dp += g0 - 10.0 * g3 + 15.0 * g4 - 6.0 * g5;
                 dv += g1 - 6.0 * g3 + 8.0 * g4 - 3.0 * g5;
@@ -673,7 +677,9 @@ struct Solver {
                 const int k = col == 0 ? 0 : (col == N + 2 ? N : col - 2);
                 a += 20.0 * ((L0(k - 1) - L0(k)) - (L0(k) - L0(k + 1))) - 15.0 * (L1(k - 1) - L1(k + 1));
             }
-            if (isxy) { gamxy[t] = a; acc[0] += hT; } else { gamyaw[t - 2 * nbx] = a; acc[1] += hT; }
+            if (isxy) gamxy[t] = a; else gamyaw[t - 2 * nbx] = a;
+            acc[0] += isxy ? hT : 0.0;
+            acc[1] += isxy ? 0.0 : hT;
         });
         if (sub_t) { sub_t[4] += ta1 - ta0; sub_t[5] += ta2 - ta1; sub_t[6] += wg.clock() - ta2; }
         chain_xy = ch[0] + hh[0];
@@ -688,26 +694,35 @@ struct Solver {
         ec_omega_h = wg.bcast(0.5 * P.rho_ter * ec_step * scale_fx);
     }
 
+    // hx / gx of the LAST evaluated trajectory (Q1: the coefficients in LDS are those of the last evaluation, also after a failed
+    // line search restored x), for updateDualVars / judgeConvergence / the caller
+    UPH_HD void refreshResiduals() {
+        wg.pfor(2, [&](int u) { fillTimes(u); });          // adjoint() has overwritten the tables with gamma
+        wg.pfor(S, [&](int s) { double dummy[3]; sampleEval<true>(s, 0, dummy); });
+    }
+
     // ------------------------------------------------------------------ innerCallback (alm_traj_opt.cpp:280-347)
     UPH_HD double eval(const double* xin, double* gout) {
         evals++;
         long long t0 = wg.clock();
         if (t_last_eval_end) cyc[5] += t0 - t_last_eval_end;      // from the end of the previous evaluation (or of the two-loop) to here
         generate(xin);
-        const double tau = xin[0];
-        const double jw = P.use_scaling ? scale_trick_jerk * scale_fx : scale_fx;      // :308-310, 322-332
+        // (values that stay alive across the evaluation's barriers are parked in scalar registers: a "uniform" double left in a
+        // VGPR competes with the sample code for registers and ends up in scratch)
+        const double tau = wg.bcast(xin[0]);
+        const double jw = wg.bcast(P.use_scaling ? scale_trick_jerk * scale_fx : scale_fx);      // :308-310, 322-332
         double js[3];
         expand(xin, jw, js);
         long long t1 = wg.clock(); cyc[0] += t1 - t0;
         last_jerk = js[0];
-        const double jerk_cost = P.use_scaling ? js[0] * scale_fx * scale_trick_jerk : js[0] * scale_fx;
+        const double jerk_cost = wg.bcast(P.use_scaling ? js[0] * scale_fx * scale_trick_jerk : js[0] * scale_fx);
         evalConsts();
         double sm[3] = {0.0, 0.0, 0.0};
         for (int s0 = 0; s0 < S; s0 += CH) {
             const int cnt = S - s0 < CH ? S - s0 : CH;
             double part[3];
             t0 = wg.clock();
-            wg.template sum<3>(cnt, part, [&](int t, double* acc) { sampleEval(s0 + t, t, acc); });
+            wg.template sum<3>(cnt, part, [&](int t, double* acc) { sampleEval<false>(s0 + t, t, acc); });
             t1 = wg.clock(); cyc[1] += t1 - t0;
             sm[0] += part[0]; sm[1] += part[1]; sm[2] += part[2];
             scatterChunk(s0, cnt);
@@ -986,8 +1001,9 @@ struct Solver {
                 // norms of the convergence test, s = x - xp and y = g - gp (stored as history column `end`), y.s, y.y, s.s,
                 // gp.gp, g.g, the steepest-descent direction, and the xp / gp update for the next search.  Writing column `end`
                 // and xp / gp before the exit tests is harmless: every exit below ends this L-BFGS call.
-                double* sc = lm_s + (size_t)end * n;
-                double* yc = lm_y + (size_t)end * n;
+                double* hr = hist + (size_t)end * hrow;
+                double* sc = hr + 2;
+                double* yc = hr + 2 + hnp;
                 double r5[5], mx2[2];
                 wg.template sumMax<5, 2>(n, r5, mx2, [&](int i, double* acc, double* mx) {
                     const double xv = x[i], gv = g[i], xo = xp[i], go = gp[i];
@@ -1016,7 +1032,8 @@ struct Solver {
                     const double fv = fx, ysv = ys;
                     wg.pfor(1, [&](int) {
                         if (0 < P.past) pf[kk % P.past] = fv;
-                        lm_ys[2 * e0] = ysv; lm_ys[2 * e0 + 1] = 1.0 / ysv; // (y.s, 1 / y.s) interleaved: one 16-byte load per chain step
+                        double* h0 = hist + (size_t)e0 * hrow;
+                        h0[0] = ysv; h0[1] = 1.0 / ysv;                      // (y.s, 1 / y.s) lead the pair's row: one 16-byte load per chain step
                     });
                 }
                 ++k;
@@ -1028,7 +1045,7 @@ struct Solver {
                     // two-loop recursion (lbfgs.hpp:687-710): a serial chain of 2*bound dot/axpy steps over the history in HBM
                     const long long tq = wg.clock();
                     cyc[7] += tq - t_last_eval_end;                 // end of evaluation -> start of the two-loop
-                    wg.twoLoop(d, g, n, lm_s, lm_y, lm_ys, pf + MAX_PAST, rec, m, end, bound, ys / yy);   // (the record buffer is idle here: it parks the alphas)
+                    wg.twoLoop(d, g, n, hist, pf + MAX_PAST, rec, m, end, bound, ys / yy);   // (the record buffer is idle here: it parks the alphas)
                     dginit = wg.bcast(pf[MAX_PAST]);                // g . d, left by the two-loop
                     t_last_eval_end = wg.clock();
                     cyc[4] += t_last_eval_end - tq;
@@ -1100,6 +1117,7 @@ struct Solver {
             int kk = 0;
             tracePush(-1.0);
             const int result = lbfgs(inner_cost, kk);
+            refreshResiduals();
             total_k += kk;
             last_ret = result;
             if (result == LBFGS_CONVERGENCE || result == LBFGS_CANCELED || result == LBFGS_STOP || result == LBFGSERR_MAXIMUMITERATION) {
@@ -1136,7 +1154,7 @@ struct Solver {
         a[2] = wg.clock();
         for (int r = 0; r < reps; r++) evalConsts();
         a[3] = wg.clock();
-        for (int r = 0; r < reps; r++) { wg.template sum<3>(cnt, part, [&](int t, double* ac) { sampleEval(t, t, ac); }); acc += part[0]; }
+        for (int r = 0; r < reps; r++) { wg.template sum<3>(cnt, part, [&](int t, double* ac) { sampleEval<false>(t, t, ac); }); acc += part[0]; }
         a[4] = wg.clock();
         for (int r = 0; r < reps; r++) scatterChunk(0, cnt);
         a[5] = wg.clock();
@@ -1149,8 +1167,8 @@ struct Solver {
             acc += absmax(g, n) + absmax(x, n);
             wg.sync();
             wg.pfor(1, [&](int) { pf[r % 3] = acc; });
-            double* sc = lm_s + (size_t)end * n;
-            double* yc = lm_y + (size_t)end * n;
+            double* sc = hist + (size_t)end * hrow + 2;
+            double* yc = sc + hnp;
             double r6[6] = {0, 0, 0, 0, 0, 0};
             wg.template sum<3>(n, r6, [&](int i, double* ac) {
                 const double sv = x[i] - xp[i], yv = g[i] - gp[i];
@@ -1160,7 +1178,7 @@ struct Solver {
             });
             acc += r6[0] + r6[3] + sqrt(dot(gp, gp, n));
             wg.sync();
-            wg.pfor(1, [&](int) { lm_ys[2 * end] = acc; });
+            wg.pfor(1, [&](int) { hist[(size_t)end * hrow] = acc; });
             (void)bound;
         }
         a[7] = wg.clock();
@@ -1180,6 +1198,7 @@ struct Solver {
         wg.pfor(n, [&](int t) { x[t] = gx0[t]; });
         double f = 0.0;
         for (int r = 0; r < repeat; r++) f = eval(x, g);
+        refreshResiduals();
         wg.pfor(n, [&](int t) { bd.gout[td.off_x + t] = g[t]; });
         storeTrajectory(st);
         wg.pfor(1, [&](int) { st.f = f; });

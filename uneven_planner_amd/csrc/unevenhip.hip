@@ -171,37 +171,49 @@ struct DevWG {
     }
     __device__ __forceinline__ double bcast(double v) const { return uni(v); }   // a value every lane read from the same LDS word
     // L-BFGS two-loop recursion (lbfgs.hpp:687-710) by wave 0 alone: d lives in registers (n <= 256 -> NQ <= 4 per lane, NQ a
-    // compile-time constant so that short problems carry no dead loads or FMAs), the history columns stream in as coalesced
-    // 512-byte rows (fetched PF = 5 chain steps ahead into a register ring, together with the pair's curvature y.s and its
-    // reciprocal), dot products are DPP wave sums, and the alpha of chain step i is parked in LDS (the idle record buffer) -- the
-    // 2*bound-step serial chain contains no barrier, no LDS and no dependent memory access.  Ring indices are stepped by
-    // compare-and-wrap (an integer modulo per step cost 25 % of the chain).  The quotient x / ys of every step is formed from
-    // the stored r = RN(1/ys) as q0 = x r, q = fma(fma(-q0, ys, x), r, q0): the closing steps of the IEEE division sequence
-    // (Markstein), three dependent FMAs on the chain instead of the full v_rcp/Newton/fixup expansion.
+    // compile-time constant so that short problems carry no dead loads or FMAs).  A history row holds one pair: (y.s, 1/(y.s)), then
+    // s and y, both zero-padded to NQ full registers (uph_common.hpp histRowDoubles), so a chain step streams its pair with
+    // unconditional 16-byte loads off ONE scalar base -- no exec masking for ragged rows, half the load instructions, one
+    // address register.  Lane l holds elements (2l, 2l+1) of every 128-element group and, for odd NQ, element 64 (NQ-1) + l.
+    // Rows are fetched PF chain steps ahead into a register ring, dot products are DPP wave sums, the alpha of chain step i is
+    // parked in LDS (the idle record buffer) -- the 2*bound-step serial chain contains no barrier and no dependent memory access.
+    // The quotient x / ys of every step is formed from the stored r = RN(1/ys) as q0 = x r, q = fma(fma(-q0, ys, x), r, q0): the
+    // closing steps of the IEEE division sequence (Markstein), three dependent FMAs on the chain.
     static __device__ __forceinline__ double divByStored(double x, double ys, double r) {
         const double q0 = x * r;
         return fma(fma(-q0, ys, x), r, q0);
     }
     template <int NQ, int PF>
-    __device__ __forceinline__ void twoLoopT(double* d, const double* g, double* dg_out, double* al_lds, int n_, const double* __restrict__ lm_s_, const double* __restrict__ lm_y_,
-                                             const double* __restrict__ lm_ys_, int m_, int end_, int bound_, double scale_) {
-        const gcptr lm_s = uniG(lm_s_), lm_y = uniG(lm_y_), lm_ys = uniG(lm_ys_);
+    __device__ __forceinline__ void twoLoopT(double* d, const double* g, double* dg_out, double* al_lds, int n_, const double* hist_, int m_, int end_, int bound_, double scale_) {
+        typedef double dbl2_t __attribute__((ext_vector_type(2)));
+        typedef const __attribute__((address_space(1))) char* gbytes;
+        constexpr int NP2 = NQ / 2;                             // 16-byte register pairs per vector
+        constexpr bool ODD = (NQ & 1) != 0;
+        constexpr int NPAD = 64 * NQ, ROWB = (2 + 2 * NPAD) * 8;
+        const gbytes hist = (gbytes)uniG(hist_);
         const int lane = flane();
         const int n = uni(n_), m = uni(m_), end = uni(end_), bound = uni(bound_);
         const double scale = uni(scale_);
+        const unsigned l16 = 16u * (unsigned)lane, l8 = 8u * (unsigned)lane;
+        // element index of register q of this lane
+        auto eidx = [&](int q) { return q < 2 * NP2 ? 128 * (q >> 1) + 2 * lane + (q & 1) : 64 * (NQ - 1) + lane; };
         double dr[NQ], sr[PF][NQ], yr[PF][NQ], ysr[PF], rysr[PF];
-        const bool okl = lane + 64 * (NQ - 1) < n;              // only the last register of a row can be ragged
 #pragma unroll
-        for (int q = 0; q < NQ; q++) dr[q] = (q < NQ - 1 || okl) ? d[lane + 64 * q] : 0.0;
+        for (int q = 0; q < NQ; q++) { const int e = eidx(q); dr[q] = e < n ? d[e] : 0.0; }
         auto fetch = [&](int slot, int j) {
-            const gcptr sj = lm_s + (size_t)j * n, yj = lm_y + (size_t)j * n;
-#pragma unroll
-            for (int q = 0; q < NQ - 1; q++) { sr[slot][q] = sj[lane + 64 * q]; yr[slot][q] = yj[lane + 64 * q]; }
-            sr[slot][NQ - 1] = okl ? sj[lane + 64 * (NQ - 1)] : 0.0;
-            yr[slot][NQ - 1] = okl ? yj[lane + 64 * (NQ - 1)] : 0.0;
-            typedef double dbl2_t __attribute__((ext_vector_type(2)));
-            const dbl2_t yr2 = *(const __attribute__((address_space(1))) dbl2_t*)(lm_ys + 2 * j);       // (y.s, 1 / y.s): one 16-byte load
+            const gbytes row = hist + (size_t)((unsigned)j * (unsigned)ROWB);
+            const dbl2_t yr2 = *(const __attribute__((address_space(1))) dbl2_t*)row;       // (y.s, 1 / y.s)
             ysr[slot] = yr2.x; rysr[slot] = yr2.y;
+#pragma unroll
+            for (int p = 0; p < NP2; p++) {
+                const dbl2_t s2 = *(const __attribute__((address_space(1))) dbl2_t*)(row + 16 + 1024 * p + l16);
+                const dbl2_t y2 = *(const __attribute__((address_space(1))) dbl2_t*)(row + 16 + NPAD * 8 + 1024 * p + l16);
+                sr[slot][2 * p] = s2.x; sr[slot][2 * p + 1] = s2.y; yr[slot][2 * p] = y2.x; yr[slot][2 * p + 1] = y2.y;
+            }
+            if (ODD) {
+                sr[slot][NQ - 1] = *(const __attribute__((address_space(1))) double*)(row + 16 + 512 * (NQ - 1) + l8);
+                yr[slot][NQ - 1] = *(const __attribute__((address_space(1))) double*)(row + 16 + NPAD * 8 + 512 * (NQ - 1) + l8);
+            }
         };
         auto rowDot = [&](const double* a, const double* b_) {
             if (NQ == 1) return a[0] * b_[0];
@@ -231,7 +243,7 @@ struct DevWG {
             for (int q = 0; q < NQ; q++) asm volatile("" : "+v"(dr[q]) : : "memory");
         };
         // ---- first loop: newest -> oldest
-        int jf = end;                                            // column being fetched
+        int jf = end;                                            // row being fetched
 #pragma unroll
         for (int u = 0; u < PF; u++) { jf = jf == 0 ? m - 1 : jf - 1; fetch(u, jf); }
         int i = 0;
@@ -251,7 +263,7 @@ struct DevWG {
         }
 #pragma unroll
         for (int q = 0; q < NQ; q++) dr[q] *= scale;
-        // ---- second loop: oldest -> newest, starting at the column the first loop ended on; step i2 pairs with first-loop step bound-1-i2
+        // ---- second loop: oldest -> newest, starting at the row the first loop ended on; step i2 pairs with first-loop step bound-1-i2
         jf = end - bound; jf = jf < 0 ? jf + m : jf;             // oldest stored pair
 #pragma unroll
         for (int u = 0; u < PF; u++) { fetch(u, jf); jf = jf + 1 == m ? 0 : jf + 1; }
@@ -272,8 +284,7 @@ struct DevWG {
         // g . d for the next line search, while d is still in registers
         double gd = 0.0;
 #pragma unroll
-        for (int q = 0; q < NQ - 1; q++) { d[lane + 64 * q] = dr[q]; gd += g[lane + 64 * q] * dr[q]; }
-        if (okl) { d[lane + 64 * (NQ - 1)] = dr[NQ - 1]; gd += g[lane + 64 * (NQ - 1)] * dr[NQ - 1]; }
+        for (int q = 0; q < NQ; q++) { const int e = eidx(q); if (e < n) { d[e] = dr[q]; gd += g[e] * dr[q]; } }
         gd = waveSum(gd);
         if (lane == 0) *dg_out = gd;
     }
@@ -355,16 +366,15 @@ struct DevWG {
         if (adj) thomasT<true>(tab, bw, lenW, bx, lenX);
         else thomasT<false>(tab, bw, lenW, bx, lenX);
     }
-    __device__ __forceinline__ void twoLoop(double* d, const double* g, int n, const double* __restrict__ lm_s, const double* __restrict__ lm_y,
-                                            const double* __restrict__ lm_ys, double* dg_out, double* al_lds, int m, int end, int bound, double scale) {
+    __device__ __forceinline__ void twoLoop(double* d, const double* g, int n, const double* __restrict__ hist, double* dg_out, double* al_lds, int m, int end, int bound, double scale) {
         if (wave == 0) {
             __builtin_amdgcn_s_setprio(3);          // a pure dependency chain: let it win the issue arbitration against throughput-bound waves
             constexpr int PF = UPH_TWOLOOP_PF;
             const int nq = uni((n + 63) >> 6);
-            if (nq == 1) twoLoopT<1, PF>(d, g, dg_out, al_lds, n, lm_s, lm_y, lm_ys, m, end, bound, scale);
-            else if (nq == 2) twoLoopT<2, PF>(d, g, dg_out, al_lds, n, lm_s, lm_y, lm_ys, m, end, bound, scale);
-            else if (nq == 3) twoLoopT<3, PF>(d, g, dg_out, al_lds, n, lm_s, lm_y, lm_ys, m, end, bound, scale);
-            else twoLoopT<4, PF>(d, g, dg_out, al_lds, n, lm_s, lm_y, lm_ys, m, end, bound, scale);
+            if (nq == 1) twoLoopT<1, PF>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
+            else if (nq == 2) twoLoopT<2, PF>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
+            else if (nq == 3) twoLoopT<3, PF>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
+            else twoLoopT<4, PF>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
@@ -466,8 +476,8 @@ struct uph_ctx {
     int lanes_forced = 0;                   // 0 = choose from the batch size
     int wps = 1;                            // workgroups of 256 lanes per CU the kernel is compiled for (1 or 2)
     int wps_forced = 0;                     // experiment knob: register-capped (2) or uncapped (1) build regardless of batch size
-    DevBuf d_lmys, d_thomas;
-    DevBuf d_desc, d_state, d_x, d_x0, d_gout, d_dual, d_res, d_scl, d_cxy, d_cyaw, d_lms, d_lmy, d_report, d_order, d_trace;
+    DevBuf d_thomas;
+    DevBuf d_desc, d_state, d_x, d_x0, d_gout, d_dual, d_res, d_scl, d_cxy, d_cyaw, d_hist, d_report, d_order, d_trace;
     int trace_cap = 0;
     std::vector<TrajState> state_host;
     // stats of the last solve
@@ -494,8 +504,7 @@ static BatchDev makeBatchDev(uph_ctx* c) {
     bd.x = c->d_x.as<double>(); bd.x0 = c->d_x0.as<double>(); bd.gout = c->d_gout.as<double>();
     bd.dual = c->d_dual.as<double>(); bd.res = c->d_res.as<double>(); bd.scl = c->d_scl.as<double>();
     bd.cxy = c->d_cxy.as<double>(); bd.cyaw = c->d_cyaw.as<double>();
-    bd.lm_s = c->d_lms.as<double>(); bd.lm_y = c->d_lmy.as<double>();
-    bd.lm_ys = c->d_lmys.as<double>();
+    bd.hist = c->d_hist.as<double>();
     bd.report = c->d_report.as<double>();
     bd.trace = c->trace_cap > 0 ? c->d_trace.as<double>() : nullptr;
     bd.trace_cap = c->trace_cap;
@@ -625,7 +634,7 @@ void uph_ctx_destroy(uph_ctx* c) {
     hipSetDevice(c->device);             // not via c->map: the map may already have been destroyed by the caller
     for (void* p : c->op_allocs) hipFree(p);
     DevBuf* bufs[] = {&c->d_ops, &c->d_desc, &c->d_state, &c->d_x, &c->d_gout, &c->d_dual, &c->d_res, &c->d_scl, &c->d_cxy, &c->d_cyaw,
-                      &c->d_lms, &c->d_lmy, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_lmys, &c->d_thomas};
+                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -682,7 +691,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         t.off_x = on; t.off_s = os; t.off_cxy = ocx; t.off_cyaw = ocy; t.off_hist = oh;
         for (int k = 0; k < 6; k++) { t.init_xy[k] = pr.init_xy[k]; t.end_xy[k] = pr.end_xy[k]; }
         for (int k = 0; k < 3; k++) { t.init_yaw[k] = pr.init_yaw[k]; t.end_yaw[k] = pr.end_yaw[k]; }
-        on += t.n; os += t.S; ocx += 12 * Nxy; ocy += 6 * Nyaw; oh += (int64_t)mem * t.n;
+        on += t.n; os += t.S; ocx += 12 * Nxy; ocy += 6 * Nyaw; oh += (int64_t)mem * histRowDoubles(t.n);
         c->fp_bytes[b] = (Solver<DevWG<64>>::ldsDoubles(Nxy, Nyaw, t.n, c->lanes, mem, c->P.int_K) + 2 * (c->lanes / 64) * DevWG<64>::MAXM) * sizeof(double);
         lds_d = std::max(lds_d, Solver<DevWG<64>>::ldsDoubles(Nxy, Nyaw, t.n, c->lanes, mem, c->P.int_K));
     }
@@ -698,7 +707,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     }
     if (c->d_desc.ensure(sizeof(TrajDesc) * B) || c->d_state.ensure(sizeof(TrajState) * B) || c->d_x.ensure(8 * on) || c->d_x0.ensure(8 * on) || c->d_gout.ensure(8 * on) ||
         c->d_dual.ensure(8 * 7 * os) || c->d_res.ensure(8 * 7 * os) || c->d_scl.ensure(8 * 7 * os) || c->d_cxy.ensure(8 * ocx) || c->d_cyaw.ensure(8 * ocy) ||
-        c->d_lms.ensure(8 * oh) || c->d_lmy.ensure(8 * oh) || c->d_lmys.ensure(16 * (size_t)mem * B) || c->d_report.ensure(8 * 7 * B) || c->d_order.ensure(4 * B) ||
+        c->d_hist.ensure(8 * oh) || c->d_report.ensure(8 * 7 * B) || c->d_order.ensure(4 * B) ||
         c->d_trace.ensure(8 * (size_t)std::max(1, c->trace_cap) * B))
         return UPH_ERR_HIP;
     // x0 = [tau | Pxy | Pyaw]  (alm_traj_opt.cpp:206-216)
@@ -750,6 +759,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     HIPCHK(hipMemcpy(c->d_order.p, c->order.data(), 4 * B, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_state.p, c->state_host.data(), sizeof(TrajState) * B, hipMemcpyHostToDevice));
     // duals = 0, residuals = 0, scales = 1 (alm_traj_opt.cpp:193-203) so that the test hooks see a defined state
+    HIPCHK(hipMemset(c->d_hist.p, 0, 8 * oh));          // the pads of the history rows must be (and stay) zero
     HIPCHK(hipMemset(c->d_dual.p, 0, 8 * 7 * os));
     HIPCHK(hipMemset(c->d_res.p, 0, 8 * 7 * os));
     std::vector<double> ones(7 * os, 1.0);

@@ -115,7 +115,7 @@ struct TrajDesc {
     int64_t off_x;              // into x0 / x_out / g_out            [sum n]
     int64_t off_s;              // into per-sample SoA blocks: block b has 7*S entries at 7*off_s, plane k at 7*off_s + k*S
     int64_t off_cxy, off_cyaw;  // into c_xy [sum 12 Nxy], c_yaw [sum 6 Nyaw]
-    int64_t off_hist;           // into lm_s / lm_y [sum mem*n]
+    int64_t off_hist;           // into hist [sum mem * histRowDoubles(n)]
     double init_xy[6], end_xy[6], init_yaw[3], end_yaw[3];   // xy: column-major 2x3 {P,V,A}
 };
 
@@ -141,9 +141,7 @@ struct BatchDev {
     double* scl;        // [7*sumS]  scale_cx planes
     double* cxy;        // [sum 12 Nxy]
     double* cyaw;       // [sum 6 Nyaw]
-    double* lm_s;       // [sum mem*n]
-    double* lm_y;
-    double* lm_ys;      // [B*2*mem]  per trajectory: (y_j . s_j, 1 / (y_j . s_j)) of every stored pair, interleaved (read by the two-loop)
+    double* hist;       // L-BFGS history, per trajectory mem rows of histRowDoubles(n): [y.s, 1/(y.s) | s padded to 64 NQ | y padded]  (pads stay zero)
     double* report;     // [B*7]
     double* trace;      // optional [B*trace_cap] diagnostic cost trace (nullptr = off)
     int trace_cap;
@@ -171,6 +169,10 @@ UPH_HD void submv2(double r0, double r1, const double* M, double p0, double p1, 
     o0 = fma(-M[1], p1, fma(-M[0], p0, r0));
     o1 = fma(-M[3], p1, fma(-M[2], p0, r1));
 }
+// L-BFGS history row of an n-variable trajectory: the pair's curvature y.s and its reciprocal, then s and y, each padded with
+// zeros to NQ = ceil(n / 64) full 64-lane registers -- the two-loop streams a pair with unconditional 16-byte loads from ONE base
+UPH_HD int histNQ(int n) { return (n + 63) >> 6; }
+UPH_HD int histRowDoubles(int n) { return 2 + 128 * histNQ(n); }
 // Block-LU factors of the MINCO knot system (minco_op_host.hpp): table entry j = {L_j, D_j^-1}, constant from j = THOMAS_J on.
 constexpr int THOMAS_J = 26;
 constexpr int THOMAS_STRIDE = 8;
