@@ -57,7 +57,7 @@ struct Solver {
     int hrow, hnp;       // history row length and padded vector length in doubles (uph_common.hpp histRowDoubles)
     const double *Wr_xy, *Wr_yaw;                       // dense knot operators [row][col] (initScaling's row gathers)
     // uniform scalars (identical in every lane)
-    double rho, scale_fx, Txy, Tyaw, last_jerk;
+    double rho, scale_fx, Txy, Tyaw, last_jerk, last_gd;
     long long hist_reads;
     long long cyc[16];
     long long t_last_eval_end;
@@ -98,7 +98,8 @@ struct Solver {
         q += nvec < Nxy + K + 2 ? Nxy + K + 2 : nvec;
         cxy = q; q += 12 * Nxy; cyaw = q; q += 6 * Nyaw;
         Gxy = q; q += 12 * Nxy; Gyaw = q; q += 6 * Nyaw;
-        rec = q;
+        wtab = q; q += 18 * (K + 1);                         // basis weights of the K + 1 in-piece sample times: [j][k][beta0, beta1, beta2]
+        rec = q;                                             // (wtab sits right before rec: scatterChunk's unmasked batch reads may run past either one's end by a few words)
         {
             size_t rd = (size_t)recd;
             const size_t knd = 4 * (size_t)(Nxy + 1) + 2 * (Nyaw + 1), adj = 4 * (size_t)(Nxy - 1) + 2 * (Nyaw - 1) + nvec;
@@ -106,7 +107,6 @@ struct Solver {
             q += rd;
         }
         rtag = (int*)(rec + (size_t)REC_FIELDS * CHP);
-        wtab = q; q += 18 * (K + 1);                         // basis weights of the K + 1 in-piece sample times: [j][k][beta0, beta1, beta2]
         ttab = q; q += THOMAS_DOUBLES;                       // block-LU factors of the knot system
         pf = q; q += MAX_PAST + 8;
         hd = q; q += 18;                                     // head / tail states {P,V,A}: init_xy[6], end_xy[6], init_yaw[3], end_yaw[3]
@@ -163,9 +163,13 @@ struct Solver {
     // sides r_j = (20 (dl+ - dl-), -15 (dl+ + dl-)) in parallel -- the known end states z_0, z_N moved to the right (- A z_0 at
     // knot 1, - C z_N at knot N-1) --, then ONE fused forward / backward sweep with the 2x2 block factors (wg.thomas).  The knot
     // states [(N+1)][v,a][dim] sit in the record buffer, which is idle until the first sample chunk.
-    UPH_HD void generate(const double* xin) {
+    // STEP: the line search's trial point x = xp + st d is formed here as well (every lane computes the positions it needs from xp and
+    // d and stores its own knot), which spares the search a pass and a barrier per trial.
+    template <bool STEP>
+    UPH_HD void generate(double* xin, double st) {
         const long long tsub_start = wg.clock();
-        const double Ttot = expC2(xin[0]);
+        const double tau_ = STEP ? fma(st, d[0], xp[0]) : xin[0];
+        const double Ttot = expC2(tau_);
         Txy = wg.bcast(Ttot / (double)Nxy);       // calTfromTau, alm_traj_opt.h:257-261 (wave-uniform: kept in scalar registers)
         Tyaw = wg.bcast(Ttot / (double)Nyaw);
         ec_iTyaw = wg.bcast(1.0 / Tyaw);
@@ -179,10 +183,18 @@ struct Solver {
             const double* h0 = isxy ? hd + (dd & 1) : hd + 12;       // {P, V, A} of the head at stride os; tail 6 (xy) / 3 (yaw) doubles further
             const double* h1 = isxy ? hd + 6 + (dd & 1) : hd + 15;
             double* z = isxy ? zxy + 4 * j + (dd & 1) : zyaw + 2 * j;      // component stride os
+            if (STEP && t == 0) xin[0] = tau_;
             if (j == 0) { z[0] = T1 * h0[os]; z[os] = T1 * T1 * h0[2 * os]; }
             else if (j == N) { z[0] = T1 * h1[os]; z[os] = T1 * T1 * h1[2 * os]; }
             else {
-                const double pm = knotPos(xin, j - 1, dd), p0 = knotPos(xin, j, dd), pp = knotPos(xin, j + 1, dd);
+                double pm, p0, pp;
+                if (STEP) {
+                    const int ix = isxy ? 1 + 2 * (j - 1) + dd : 1 + 2 * (Nxy - 1) + (j - 1), ws = isxy ? 2 : 1;     // x index of knot j, stride between knots
+                    p0 = fma(st, d[ix], xp[ix]);
+                    pm = j == 1 ? h0[0] : fma(st, d[ix - ws], xp[ix - ws]);
+                    pp = j == N - 1 ? h1[0] : fma(st, d[ix + ws], xp[ix + ws]);
+                    xin[ix] = p0;
+                } else { pm = knotPos(xin, j - 1, dd); p0 = knotPos(xin, j, dd); pp = knotPos(xin, j + 1, dd); }
                 const double dp = pp - p0, dm = p0 - pm;
                 double r0 = 20.0 * (dp - dm), r1 = -15.0 * (dp + dm);
                 if (j == 1) { const double v0 = T1 * h0[os], a0 = T1 * T1 * h0[2 * os]; r0 += 8.0 * v0 + a0; r1 += 7.0 * v0 + a0; }
@@ -559,19 +571,20 @@ struct Solver {
                 const int jo = ja;                           // slot - jo = the sample's in-piece index j
                 if (ja < 0) ja = 0;
                 if (jb > cnt) jb = cnt;
-                const double* rp = rec + dd * CHP;           // grad_p[dd], grad_v[dd] two rows on, grad_a[dd] four
-                const double* wq = wtab + 3 * q - 18 * jo;   // weights of (j, q) at wq[18 * slot]
+                // every operand of a batch is read at base + constant (no per-element clamping or address arithmetic); reads past the
+                // piece's last slot land in neighbouring LDS words of the same allocation and are discarded by the selects below
+                const double* r0 = rec + dd * CHP + ja;      // grad_p[dd]; grad_v[dd] two rows on, grad_a[dd] four
+                const double* w = wtab + 3 * q + 18 * (ja - jo);
                 double a = 0.0;
-                for (int sb_ = ja; sb_ < jb; sb_ += UPH_SC_XB) {
+                for (int len = jb - ja; len > 0; len -= UPH_SC_XB, r0 += UPH_SC_XB, w += 18 * UPH_SC_XB) {
                     double e0[UPH_SC_XB], e1[UPH_SC_XB], e2[UPH_SC_XB], w0[UPH_SC_XB], w1[UPH_SC_XB], w2[UPH_SC_XB];
 #pragma unroll
                     for (int u = 0; u < UPH_SC_XB; u++) {
-                        const int sl = sb_ + u < jb ? sb_ + u : jb - 1;
-                        e0[u] = rp[sl]; e1[u] = rp[2 * CHP + sl]; e2[u] = rp[4 * CHP + sl];
-                        w0[u] = wq[18 * sl]; w1[u] = wq[18 * sl + 1]; w2[u] = wq[18 * sl + 2];
+                        e0[u] = r0[u]; e1[u] = r0[2 * CHP + u]; e2[u] = r0[4 * CHP + u];
+                        w0[u] = w[18 * u]; w1[u] = w[18 * u + 1]; w2[u] = w[18 * u + 2];
                     }
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_XB; u++) a += sb_ + u < jb ? (w0[u] * e0[u] + w1[u] * e1[u] + w2[u] * e2[u]) : 0.0;
+                    for (int u = 0; u < UPH_SC_XB; u++) a += u < len ? (w0[u] * e0[u] + w1[u] * e1[u] + w2[u] * e2[u]) : 0.0;
                 }
                 Gxy[12 * i + r] += a;
             } else {
@@ -587,15 +600,16 @@ struct Solver {
                 if (sa < 0) sa = 0;
                 if (sb > cnt) sb = cnt;
                 if (sb < sa) sb = sa;
-                const double* rv = rec + (6 + k) * CHP;
+                const double* rv = rec + (6 + k) * CHP + sa;
+                const int* tg = rtag + sa;
                 double a = 0.0;
-                for (int s8 = sa; s8 < sb; s8 += UPH_SC_YB) {
+                for (int len = sb - sa; len > 0; len -= UPH_SC_YB, rv += UPH_SC_YB, tg += UPH_SC_YB) {
                     int tg_[UPH_SC_YB];
                     double vv[UPH_SC_YB];
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_YB; u++) { const int slot = s8 + u < sb ? s8 + u : sb - 1; tg_[u] = rtag[slot]; vv[u] = rv[slot]; }
+                    for (int u = 0; u < UPH_SC_YB; u++) { tg_[u] = tg[u]; vv[u] = rv[u]; }
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_YB; u++) a += ((s8 + u < sb) && (tg_[u] == m)) ? vv[u] : 0.0;
+                    for (int u = 0; u < UPH_SC_YB; u++) a += ((u < len) && (tg_[u] == m)) ? vv[u] : 0.0;
                 }
                 Gyaw[6 * m + k] += a;
             }
@@ -605,7 +619,9 @@ struct Solver {
     // ------------------------------------------------------------------ adjoint: (dK/dc, direct dK/dT sums) -> gradient w.r.t. (q, T)
     // calGradCTtoQT (se2traj.hpp:751-816) through the knot system.  On return gamxy / gamyaw hold gamma = M^T (G T^-k) laid out
     // like beta; chain_xy / chain_yaw = sum_i dW/dT_i without the direct parts (header comment).
-    UPH_HD void adjoint(double& chain_xy, double& chain_yaw) {
+    // gout != nullptr: the way-point entries of the gradient are written straight from gamma (alm_traj_opt.cpp:336-337) and gd_out
+    // receives sum_{t >= 1} gout[t] d[t] (the caller adds the tau entry): g . d for the line search without a pass of its own.
+    UPH_HD void adjoint(double& chain_xy, double& chain_yaw, double* gout = nullptr, double* gd_out = nullptr) {
         const double Tx = Txy, Ty = Tyaw, itx = wg.bcast(1.0 / Txy), ity = wg.bcast(1.0 / Tyaw);
         const long long ta0 = wg.clock();
         const int nbx = Nxy + 5, nby = Nyaw + 5;
@@ -657,8 +673,8 @@ struct Solver {
         const long long ta2 = wg.clock();
         // gamma = R^T lambda + direct parts: a way-point / end position p_k enters r_{k-1}, r_k, r_{k+1}; the end states enter r_1
         // (- A z_0) and r_{N-1} (- C z_N).  The four V / A columns also give <gamma, d b~/dT> (V scales with T, A with T^2).
-        double hh[2];
-        wg.template sum<2>(nvec, hh, [&](int t, double* acc) {
+        double hh[3];
+        wg.template sum<3>(nvec, hh, [&](int t, double* acc) {
             const bool isxy = t < 2 * nbx;
             const int col = isxy ? (t >> 1) : t - 2 * nbx, dd = isxy ? (t & 1) : 0, N = isxy ? Nxy : Nyaw;
             const int ks = isxy ? 4 : 2, cs = isxy ? 2 : 1;
@@ -680,7 +696,13 @@ struct Solver {
             if (isxy) gamxy[t] = a; else gamyaw[t - 2 * nbx] = a;
             acc[0] += isxy ? hT : 0.0;
             acc[1] += isxy ? 0.0 : hT;
+            if (gout != nullptr && col >= 3 && col <= N + 1) {
+                const int ix = isxy ? 1 + 2 * (col - 3) + dd : 1 + 2 * (Nxy - 1) + (col - 3);
+                gout[ix] = a;
+                acc[2] += a * d[ix];
+            }
         });
+        if (gd_out) *gd_out = hh[2];
         if (sub_t) { sub_t[4] += ta1 - ta0; sub_t[5] += ta2 - ta1; sub_t[6] += wg.clock() - ta2; }
         chain_xy = ch[0] + hh[0];
         chain_yaw = ch[1] + hh[1];
@@ -702,11 +724,13 @@ struct Solver {
     }
 
     // ------------------------------------------------------------------ innerCallback (alm_traj_opt.cpp:280-347)
-    UPH_HD double eval(const double* xin, double* gout) {
+    // STEP: evaluates at x = xp + st d and leaves that point in xin (see generate).  last_gd = grad f . d afterwards.
+    template <bool STEP>
+    UPH_HD double eval(double* xin, double* gout, double st = 0.0) {
         evals++;
         long long t0 = wg.clock();
         if (t_last_eval_end) cyc[5] += t0 - t_last_eval_end;      // from the end of the previous evaluation (or of the two-loop) to here
-        generate(xin);
+        generate<STEP>(xin, st);
         // (values that stay alive across the evaluation's barriers are parked in scalar registers: a "uniform" double left in a
         // VGPR competes with the sample code for registers and ends up in scratch)
         const double tau = wg.bcast(xin[0]);
@@ -729,29 +753,23 @@ struct Solver {
             cyc[2] += wg.clock() - t1;
         }
         t1 = wg.clock();
-        double chx, chy;
-        adjoint(chx, chy);
+        double chx, chy, gdw;
+        adjoint(chx, chy, gout, &gdw);
         t0 = wg.clock(); cyc[3] += t0 - t1;
         const double gTx = js[1] * jw + sm[1] + chx;       // sum_i gdTxy(i) after calGradCTtoQT
         const double gTy = js[2] * jw + sm[2] + chy;
-        wg.pfor(n, [&](int t) {
-            if (t == 0) {
-                const double grad_Tsum = P.rho_T * scale_fx + gTx / Nxy + gTy / Nyaw;     // :341-344
-                gout[0] = grad_Tsum * getTtoTauGrad(tau);
-            } else if (t < 1 + 2 * (Nxy - 1)) {
-                gout[t] = gamxy[3 * 2 + (t - 1)];                                         // :336  (col 3+w, dim d) -> [(3+w)*2+d]
-            } else {
-                gout[t] = gamyaw[3 + (t - 1 - 2 * (Nxy - 1))];
-            }
-        });
+        const double grad_Tsum = P.rho_T * scale_fx + gTx / Nxy + gTy / Nyaw;             // :341-344
+        const double g0 = wg.bcast(grad_Tsum * getTtoTauGrad(tau));
+        wg.pfor(1, [&](int) { gout[0] = g0; });
+        last_gd = wg.bcast(gdw + g0 * d[0]);
         const double tau_cost = P.rho_T * expC2(tau) * scale_fx;                          // :340
         t_last_eval_end = wg.clock();
         return wg.bcast(jerk_cost + sm[0] + tau_cost);                                    // :346
     }
 
     // ------------------------------------------------------------------ initScaling (alm_traj_opt.cpp:349-661)
-    UPH_HD void initScaling(const double* x0) {
-        generate(x0);
+    UPH_HD void initScaling(double* x0) {
+        generate<false>(x0, 0.0);
         const double tau = x0[0];
         const double dTau = getTtoTauGrad(tau);
         // objective scale (:365-370, 507-519, 627-653): jerk + rho_ter*int sigma^2 + rho_T*T, no scale_trick_jerk
@@ -946,9 +964,7 @@ struct Solver {
         const double dgtest = wg.bcast(P.f_dec_coeff * dginit);
         const double dstest = wg.bcast(P.s_curv_coeff * dginit);
         while (true) {
-            const double st = stp;
-            wg.pfor(n, [&](int i) { x[i] = xp[i] + st * d[i]; });
-            f = eval(x, g);
+            f = eval<true>(x, g, stp);                                  // x = xp + stp d, f(x), g(x), last_gd = g . d
             ++count;
             if (isinf(f) || isnan(f)) return LBFGSERR_INVALID_FUNCVAL;
             if (P.past > 0 && fabs(finit - f) / (fabs(finit) + 1.0) < P.delta / P.past) return count;   // :327-330
@@ -956,7 +972,7 @@ struct Solver {
                 nu = stp;
                 brackt = true;
             } else {
-                if (dot(g, d, n) < dstest) mu = stp;
+                if (last_gd < dstest) mu = stp;
                 else return count;
             }
             if (P.max_linesearch <= count) return LBFGSERR_MAXIMUMLINESEARCH;
@@ -977,7 +993,7 @@ struct Solver {
         int ret, k = 0, ls, end, bound;
         double step, fx, ys, yy;
         const int m = mem;
-        fx = eval(x, g);
+        fx = eval<false>(x, g);
         wg.pfor(n + 1, [&](int i) { if (i < n) { d[i] = -g[i]; xp[i] = x[i]; gp[i] = g[i]; } else pf[0] = fx; });
         double gnorm_inf = absmax(g, n), xnorm_inf = absmax(x, n);
         if (gnorm_inf / dmax(1.0, xnorm_inf) < P.g_epsilon) {
@@ -1004,6 +1020,7 @@ struct Solver {
                 double* hr = hist + (size_t)end * hrow;
                 double* sc = hr + 2;
                 double* yc = hr + 2 + hnp;
+                const double pf_old = (0 < P.past && P.past <= k) ? wg.bcast(pf[k % P.past]) : 0.0;      // read before the pass' barrier: lane 0 may overwrite it afterwards
                 double r5[5], mx2[2];
                 wg.template sumMax<5, 2>(n, r5, mx2, [&](int i, double* acc, double* mx) {
                     const double xv = x[i], gv = g[i], xo = xp[i], go = gp[i];
@@ -1019,10 +1036,9 @@ struct Solver {
                 if (gnorm_inf / dmax(1.0, xnorm_inf) < P.g_epsilon) { ret = LBFGS_CONVERGENCE; break; }
                 if (0 < P.past) {
                     if (P.past <= k) {
-                        const double rate = fabs(pf[k % P.past] - fx) / dmax(1.0, fabs(fx));
+                        const double rate = fabs(pf_old - fx) / dmax(1.0, fabs(fx));
                         if (rate < P.delta) { ret = LBFGS_STOP; break; }
                     }
-                    wg.sync();                                               // every lane has read pf before it is overwritten
                 }
                 if (P.inner_max_iter != 0 && P.inner_max_iter <= k) { ret = LBFGSERR_MAXIMUMITERATION; break; }
                 ys = r5[0]; yy = r5[1];
@@ -1148,7 +1164,7 @@ struct Solver {
         double acc = 0.0, js[3], part[3], c1, c2;
         const int cnt = S < CH ? S : CH;
         a[0] = wg.clock();
-        for (int r = 0; r < reps; r++) generate(x);
+        for (int r = 0; r < reps; r++) generate<false>(x, 0.0);
         a[1] = wg.clock();
         for (int r = 0; r < reps; r++) { expand(x, 1.0, js); acc += js[0]; }
         a[2] = wg.clock();
@@ -1197,7 +1213,7 @@ struct Solver {
         rho = wg.bcast(st.rho); scale_fx = wg.bcast(st.scale_fx);
         wg.pfor(n, [&](int t) { x[t] = gx0[t]; });
         double f = 0.0;
-        for (int r = 0; r < repeat; r++) f = eval(x, g);
+        for (int r = 0; r < repeat; r++) f = eval<false>(x, g);
         refreshResiduals();
         wg.pfor(n, [&](int t) { bd.gout[td.off_x + t] = g[t]; });
         storeTrajectory(st);
