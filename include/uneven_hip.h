@@ -187,6 +187,21 @@ int uph_init_scaling_batch(uph_ctx* c);
 int uph_microbench_batch(uph_ctx* c, int32_t reps);
 /* overwrite resident duals / scales (packed in the reference's order; any pointer may be NULL) */
 int uph_batch_set_state(uph_ctx* c, const double* lambda, const double* mu, const double* scale_cx, const double* scale_fx, const double* rho);
+/* ---- test hooks of the teacher-forced late-state tests (tests/test_gpu_forced.py): drive the device state machine from a state the
+ * CPU oracle dumped, one L-BFGS iteration / one ALM pass at a time */
+/* overwrite the resident x (packed like x_final) */
+int uph_batch_set_x(uph_ctx* c, const double* x_packed);
+/* the ALM loop of optimizeSE2Traj (alm_traj_opt.cpp:234-271) from the RESIDENT x, duals, scales and rho -- no reset, no initScaling --
+ * for at most max_passes passes (0 = until it ends); a solve stopped by the cap reports ret_code 3 */
+int uph_batch_alm_passes(uph_ctx* c, int32_t max_passes);
+/* L-BFGS state at the top of the iteration loop (lbfgs.hpp:555): g, d packed like x; pf [B][UPH_MAX_PAST]; the history as the
+ * reference holds it (lm_s / lm_y column j of trajectory b at off_b + j*n, off_b = mem * sum of the n before b; lm_ys [B][mem]);
+ * scal5 [B][5] = step, fx, k, end, bound */
+int uph_batch_set_lbfgs_state(uph_ctx* c, const double* g, const double* d, const double* pf, const double* lm_s, const double* lm_y, const double* lm_ys, const double* scal5);
+/* continue from that state for at most `budget` iterations (< 0: until the loop ends); finish_pass: then react as the ALM loop does */
+int uph_batch_lbfgs_resume(uph_ctx* c, int32_t budget, int32_t finish_pass);
+/* state afterwards; scal8 [B][8] = step, fx, k, end, bound, L-BFGS code (999 = budget ran out), accepted, converged */
+int uph_batch_get_lbfgs_state(uph_ctx* c, double* g, double* d, double* pf, double* lm_s, double* lm_y, double* lm_ys, double* scal8);
 /* post-solve feasibility report per trajectory: out[B][7] = max vx, ax, ay, cur, att(-cos xi), sigma, non-holonomic error */
 int uph_report_batch(uph_ctx* c, double* out7);
 

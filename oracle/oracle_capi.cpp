@@ -301,6 +301,12 @@ int orc_alm_get_pass(void* h, int i, double* x_in, double* x_out, double* lambda
     if (scal) { scal[0] = r.rho_in; scal[1] = r.rho_out; scal[2] = r.cost; scal[3] = r.ret; scal[4] = r.k; scal[5] = r.converged; }
     return 0;
 }
+// updateDualVars + judgeConvergence on the object's current residuals (what the ALM loop does after an accepted L-BFGS code)
+int orc_alm_finish_pass(void* h) {
+    AlmTrajOpt& a = ((OrcAlm*)h)->opt;
+    a.updateDualVars();
+    return a.judgeConvergence() ? 1 : 0;
+}
 // ONE ALM pass from x with the object's current duals / scales / rho: lbfgs_optimize, then (if the ALM accepts the code) updateDualVars and
 // judgeConvergence.  out = {lbfgs code, k, accepted, converged, cost}
 void orc_alm_pass(void* h, int n, double* x, double* out5) {

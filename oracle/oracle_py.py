@@ -92,6 +92,8 @@ def lib():
         L.orc_alm_get_pass.restype = i
         L.orc_alm_get_pass.argtypes = [vp, i] + [dp] * 9
         L.orc_alm_pass.argtypes = [vp, i, dp, dp]
+        L.orc_alm_finish_pass.restype = i
+        L.orc_alm_finish_pass.argtypes = [vp]
         L.orc_alm_get_trace.restype = i
         L.orc_alm_get_trace.argtypes = [vp, dp, i]
         L.orc_mapbuilder_create.restype = vp
@@ -324,6 +326,10 @@ class OracleALM:
             r.update(rho_in=scal[0], rho_out=scal[1], cost=scal[2], ret=int(scal[3]), k=int(scal[4]), converged=int(scal[5]))
             out.append(r)
         return out
+
+    def finish_pass(self):
+        """what the ALM loop does after an accepted L-BFGS code: updateDualVars, then judgeConvergence (alm_traj_opt.cpp:257-259)"""
+        return int(self.L.orc_alm_finish_pass(self.h))
 
     def alm_pass(self, x):
         """ONE ALM pass from x with the current duals / scales / rho.  Returns dict(ret, k, accepted, converged, cost, x)"""

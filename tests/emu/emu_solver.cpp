@@ -140,6 +140,9 @@ struct HostWG {
 };
 
 static std::vector<double> g_trace;
+// teacher-forced hooks (modes 4 / 5 of emu_run): pass cap, iteration budget, finish flag and the in/out state arrays
+static int g_cap = 0, g_budget = 0, g_finish = 0;
+static double *g_hg = nullptr, *g_hd = nullptr, *g_hpf = nullptr, *g_hs = nullptr, *g_hy = nullptr, *g_hys = nullptr, *g_hscal = nullptr;
 
 struct Emu {
     GridDev grid;
@@ -175,6 +178,10 @@ void* emu_create(const double* mp11, const double* cells4, const double* op21) {
 }
 void emu_destroy(void* h) { delete (Emu*)h; }
 void emu_set_lanes(int lanes) { g_lanes = lanes; }
+// g, d [n]; pf [8]; lm_s / lm_y [mem][n]; lm_ys [mem]; scal [8]: in step, fx, k, end, bound -> out + code, accepted, converged
+void emu_set_hook(int cap, int budget, int finish, double* g, double* d, double* pf8, double* lm_s, double* lm_y, double* lm_ys, double* scal8) {
+    g_cap = cap; g_budget = budget; g_finish = finish; g_hg = g; g_hd = d; g_hpf = pf8; g_hs = lm_s; g_hy = lm_y; g_hys = lm_ys; g_hscal = scal8;
+}
 
 void emu_terrain(void* h, const double* pos, int n, double* values, double* grads) {
     Emu* e = (Emu*)h;
@@ -186,7 +193,8 @@ void emu_terrain(void* h, const double* pos, int n, double* values, double* grad
     }
 }
 
-// mode 0: eval at x (state as given); 1: initScaling at x; 2: full optimize from x; 3: optimize then report
+// mode 0: eval at x (state as given); 1: initScaling at x; 2: full optimize from x; 3: optimize then report;
+// 4: ALM passes from the given x / duals / scales / rho, at most g_cap passes (no reset, no initScaling); 5: resume the L-BFGS loop from the hook state
 // state arrays in the reference's order: lambda[S], mu[6S] (sample-major), scale_cx[7S] (7 per sample); io = in/out
 // scal[8]: in: rho, scale_fx; out: rho, scale_fx, f, jerk, Txy, Tyaw, (unused)   istat[6]: ret, alm_iters, lbfgs_iters, evals, last_ret, hist_reads
 void emu_run(void* h, int mode, int n_inner_xy, int n_inner_yaw, const double* init_xy, const double* end_xy, const double* init_yaw,
@@ -223,8 +231,34 @@ void emu_run(void* h, int mode, int n_inner_xy, int n_inner_yaw, const double* i
     std::vector<double> lds(Solver<HostWG>::ldsDoubles(td.Nxy, td.Nyaw, n, g_lanes, e->P.mem_size, e->P.int_K) + 64);
     HostWG wg;
     Solver<HostWG> sol(wg, e->grid, e->P, bd, 0, lds.data());
+    std::vector<double> rsd(n, 0.0), rs(24, 0.0);
+    bd.rs_d = rsd.data(); bd.rs = rs.data();
     if (mode == 0) sol.evalOnly(st, 1);
     else if (mode == 1) sol.scalingOnly(st);
+    else if (mode == 4) sol.optimize(st, g_cap);
+    else if (mode == 5) {
+        const int mem = e->P.mem_size, rowd = histRowDoubles(n), np = 64 * histNQ(n);
+        for (int j = 0; j < mem; j++) {
+            double* row = hist.data() + (size_t)j * rowd;
+            row[0] = g_hys[j]; row[1] = 1.0 / g_hys[j];
+            std::memcpy(row + 2, g_hs + (size_t)j * n, 8 * n);
+            std::memcpy(row + 2 + np, g_hy + (size_t)j * n, 8 * n);
+        }
+        std::memcpy(gout.data(), g_hg, 8 * n);
+        std::memcpy(rsd.data(), g_hd, 8 * n);
+        for (int q = 0; q < 5; q++) rs[q] = g_hscal[q];
+        for (int q = 0; q < 8; q++) rs[8 + q] = g_hpf[q];
+        sol.resumeHook(st, g_budget < 0 ? (1 << 28) : g_budget, g_finish);
+        for (int j = 0; j < mem; j++) {
+            const double* row = hist.data() + (size_t)j * rowd;
+            g_hys[j] = row[0];
+            std::memcpy(g_hs + (size_t)j * n, row + 2, 8 * n);
+            std::memcpy(g_hy + (size_t)j * n, row + 2 + np, 8 * n);
+        }
+        std::memcpy(g_hg, gout.data(), 8 * n);
+        std::memcpy(g_hd, rsd.data(), 8 * n);
+        for (int q = 0; q < 8; q++) { g_hscal[q] = rs[q]; g_hpf[q] = rs[8 + q]; }
+    }
     else { sol.prepare(st); sol.optimize(st); if (mode == 3) sol.report(st); }
     std::memcpy(x_io, xg.data(), 8 * n);
     std::memcpy(g_out, gout.data(), 8 * n);

@@ -82,6 +82,11 @@ SYMBOLS = {
     "uph_microbench_batch": (C.c_int, [_VP, _I32]),
     "uph_batch_set_state": (C.c_int, [_VP, DP, DP, DP, DP, DP]),
     "uph_report_batch": (C.c_int, [_VP, DP]),
+    "uph_batch_set_x": (C.c_int, [_VP, DP]),
+    "uph_batch_alm_passes": (C.c_int, [_VP, _I32]),
+    "uph_batch_set_lbfgs_state": (C.c_int, [_VP, DP, DP, DP, DP, DP, DP, DP]),
+    "uph_batch_lbfgs_resume": (C.c_int, [_VP, _I32, _I32]),
+    "uph_batch_get_lbfgs_state": (C.c_int, [_VP, DP, DP, DP, DP, DP, DP, DP]),
 }
 
 _LIB = None

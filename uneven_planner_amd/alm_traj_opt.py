@@ -226,6 +226,53 @@ class ALMTrajOpt:
         p = lambda v: _dp(v) if v is not None else None
         _lib.check(self.L.uph_batch_set_state(self.h, p(a), p(b), p(c), p(d), p(e)), "uph_batch_set_state")
 
+    # teacher-forced late-state hooks (states as oracle.OracleALM.capture() returns them) ---------------------------------
+    MAX_PAST = 8
+
+    def set_x(self, xs):
+        xp = np.ascontiguousarray(np.concatenate(xs), dtype=np.float64)
+        _lib.check(self.L.uph_batch_set_x(self.h, _dp(xp)), "uph_batch_set_x")
+
+    def alm_passes(self, max_passes=0):
+        """the ALM loop from the resident x / duals / scales / rho (no reset, no initScaling), at most max_passes passes"""
+        _lib.check(self.L.uph_batch_alm_passes(self.h, int(max_passes)), "uph_batch_alm_passes")
+
+    def set_lbfgs_state(self, states):
+        """states: one dict per uploaded trajectory with x, g, d, pf, lm_ys, lm_s (mem, n), lm_y, step, fx, k, end, bound"""
+        cat = lambda key: np.ascontiguousarray(np.concatenate([np.asarray(st[key], dtype=np.float64).ravel() for st in states]))
+        pf = np.zeros((self._B, self.MAX_PAST))
+        for i, st in enumerate(states):
+            pf[i, :len(st["pf"])] = st["pf"]
+        scal = np.array([[st["step"], st["fx"], st["k"], st["end"], st["bound"]] for st in states], dtype=np.float64)
+        self.set_x([st["x"] for st in states])
+        g, d, ls, ly, ys = cat("g"), cat("d"), cat("lm_s"), cat("lm_y"), cat("lm_ys")
+        _lib.check(self.L.uph_batch_set_lbfgs_state(self.h, _dp(g), _dp(d), _dp(pf), _dp(ls), _dp(ly), _dp(ys), _dp(scal)), "uph_batch_set_lbfgs_state")
+
+    def lbfgs_resume(self, budget, finish_pass=False):
+        _lib.check(self.L.uph_batch_lbfgs_resume(self.h, int(budget), int(bool(finish_pass))), "uph_batch_lbfgs_resume")
+
+    def get_lbfgs_state(self):
+        """list of state dicts (same keys as set_lbfgs_state + code, accepted, converged); x and the duals via download()"""
+        mem = int(self.mem_size)
+        n_tot = sum(s["n"] for s in self._sizes)
+        g, d = np.zeros(n_tot), np.zeros(n_tot)
+        pf = np.zeros((self._B, self.MAX_PAST))
+        ls, ly, ys = np.zeros(mem * n_tot), np.zeros(mem * n_tot), np.zeros((self._B, mem))
+        scal = np.zeros((self._B, 8))
+        _lib.check(self.L.uph_batch_get_lbfgs_state(self.h, _dp(g), _dp(d), _dp(pf), _dp(ls), _dp(ly), _dp(ys), _dp(scal)), "uph_batch_get_lbfgs_state")
+        x = self.download()
+        out, o, oh = [], 0, 0
+        for i, s in enumerate(self._sizes):
+            n = s["n"]
+            out.append(dict(x=x[i]["x"], g=g[o:o + n].copy(), d=d[o:o + n].copy(), pf=pf[i, :max(1, int(self.past))].copy(), lm_ys=ys[i].copy(),
+                            lm_s=ls[oh:oh + mem * n].reshape(mem, n).copy(), lm_y=ly[oh:oh + mem * n].reshape(mem, n).copy(),
+                            step=scal[i, 0], fx=scal[i, 1], k=int(scal[i, 2]), end=int(scal[i, 3]), bound=int(scal[i, 4]), code=int(scal[i, 5]),
+                            accepted=int(scal[i, 6]), converged=int(scal[i, 7]), hx=x[i]["hx"], gx=x[i]["gx"], lam=x[i]["lam"], mu=x[i]["mu"],
+                            rho=x[i]["rho_final"]))
+            o += n
+            oh += mem * n
+        return out
+
     def set_trace(self, cap):
         _lib.check(self.L.uph_ctx_set_trace(self.h, int(cap)), "uph_ctx_set_trace")
         self._trace_cap = int(cap)

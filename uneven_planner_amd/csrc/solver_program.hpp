@@ -989,21 +989,42 @@ struct Solver {
     }
 
     // ------------------------------------------------------------------ L-BFGS (lbfgs.hpp:439-722); progress callback = earlyExit (alm_traj_opt.cpp:1016)
-    UPH_HD int lbfgs(double& f_out, int& k_out) {
-        int ret, k = 0, ls, end, bound;
-        double step, fx, ys, yy;
+    // RESUME (test hook of the teacher-forced late-state tests): instead of starting at x, the loop is entered at its top with a given
+    // state -- x = xp, g = gp, d, the history ring, pf (all placed by resumeHook) and the scalars of ResumeIO -- and left again after
+    // at most `budget` iterations (return code LBFGS_RUNNING_HOOK) with the state of the next loop top written back.
+    struct ResumeIO { double step, fx; int k, end, bound, budget; };
+    static constexpr int LBFGS_RUNNING_HOOK = 999;
+    template <bool RESUME>
+    UPH_HD int lbfgs(double& f_out, int& k_out, ResumeIO* io = nullptr) {
+        int ret = 0, k = 0, ls, end = 0, bound = 0, budget = 0;
+        double step = 0.0, fx = 0.0, ys, yy, dginit = 0.0;
         const int m = mem;
-        fx = eval<false>(x, g);
-        wg.pfor(n + 1, [&](int i) { if (i < n) { d[i] = -g[i]; xp[i] = x[i]; gp[i] = g[i]; } else pf[0] = fx; });
-        double gnorm_inf = absmax(g, n), xnorm_inf = absmax(x, n);
-        if (gnorm_inf / dmax(1.0, xnorm_inf) < P.g_epsilon) {
-            ret = LBFGS_CONVERGENCE;
+        bool run = true;
+        if constexpr (RESUME) {
+            step = io->step; fx = io->fx; k = io->k; end = io->end; bound = io->bound; budget = io->budget;
+            wg.pfor(n, [&](int i) { xp[i] = x[i]; gp[i] = g[i]; });
+            dginit = dot(g, d, n);
         } else {
-            const double dd0 = dot(d, d, n);
-            step = 1.0 / sqrt(dd0);
-            double dginit = -dd0;                                            // gp . d with d = -g
-            k = 1; end = 0; bound = 0;
+            fx = eval<false>(x, g);
+            wg.pfor(n + 1, [&](int i) { if (i < n) { d[i] = -g[i]; xp[i] = x[i]; gp[i] = g[i]; } else pf[0] = fx; });
+            const double gnorm0 = absmax(g, n), xnorm0 = absmax(x, n);
+            if (gnorm0 / dmax(1.0, xnorm0) < P.g_epsilon) {
+                ret = LBFGS_CONVERGENCE;
+                run = false;
+            } else {
+                const double dd0 = dot(d, d, n);
+                step = 1.0 / sqrt(dd0);
+                dginit = -dd0;                                               // gp . d with d = -g
+                k = 1; end = 0; bound = 0;
+            }
+        }
+        double gnorm_inf, xnorm_inf;
+        if (run) {
             while (true) {
+                if constexpr (RESUME) {
+                    if (budget == 0) { ret = LBFGS_RUNNING_HOOK; break; }
+                    budget--;
+                }
                 // xp / gp hold the iterate the search starts from (initial copy above, afterwards the bookkeeping pass below)
                 ls = lineSearch(fx, step, P.min_step, P.max_step, dginit);
                 if (ls < 0) {
@@ -1070,6 +1091,7 @@ struct Solver {
                 step = 1.0;
             }
         }
+        if constexpr (RESUME) { io->step = step; io->fx = fx; io->k = k; io->end = end; io->bound = bound; }
         f_out = fx;
         k_out = k;
         return ret;
@@ -1121,7 +1143,8 @@ struct Solver {
     }
 
     // second half (alm_traj_opt.cpp:234-278): the ALM loop.  Expects prepare() to have run on this trajectory.
-    UPH_HD void optimize(TrajState& st) {
+    // cap > 0 (test hook): stop after `cap` ALM passes with ret_code 3 unless the solve ended before
+    UPH_HD void optimize(TrajState& st, int cap = 0) {
         double* gx0 = bd.x + td.off_x;
         rho = wg.bcast(st.rho);
         scale_fx = wg.bcast(st.scale_fx);
@@ -1132,7 +1155,7 @@ struct Solver {
         while (true) {                                                    // :234-271
             int kk = 0;
             tracePush(-1.0);
-            const int result = lbfgs(inner_cost, kk);
+            const int result = lbfgs<false>(inner_cost, kk);
             refreshResiduals();
             total_k += kk;
             last_ret = result;
@@ -1142,6 +1165,7 @@ struct Solver {
             updateDualVars();                                             // :257
             if (judgeConvergence()) break;                                // :259
             if (++iter > P.max_iter) { ret_code = 2; break; }             // :265
+            if (cap > 0 && iter >= cap) { ret_code = 3; break; }
         }
         wg.pfor(n, [&](int t) { gx0[t] = x[t]; bd.gout[td.off_x + t] = g[t]; });
         cyc[6] = wg.clock() - tstart;
@@ -1149,6 +1173,36 @@ struct Solver {
         wg.pfor(1, [&](int) {
             st.ret_code = ret_code; st.alm_iters = iter; st.lbfgs_iters = total_k; st.last_lbfgs_ret = last_ret; st.f = inner_cost;
         });
+    }
+
+    // test hook: continue the L-BFGS iteration loop from a state placed in HBM by the host (uph_batch_set_lbfgs_state) for at most
+    // `budget` iterations; finish != 0: when the loop ends by itself, react as the ALM loop would (accepted code -> updateDualVars +
+    // judgeConvergence).  rs[24] per trajectory: 0 step, 1 fx, 2 k, 3 end, 4 bound | out: 5 code, 6 accepted, 7 converged | 8.. pf
+    UPH_HD void resumeHook(TrajState& st, int budget, int finish) {
+        double* gx = bd.x + td.off_x;
+        double* gg = bd.gout + td.off_x;
+        double* gd = bd.rs_d + td.off_x;
+        double* rs = bd.rs + (size_t)bidx * 24;
+        rho = wg.bcast(st.rho); scale_fx = wg.bcast(st.scale_fx);
+        wg.pfor(n + MAX_PAST, [&](int t) { if (t < n) { x[t] = gx[t]; g[t] = gg[t]; d[t] = gd[t]; } else pf[t - n] = rs[8 + t - n]; });
+        ResumeIO io;
+        io.step = wg.bcast(rs[0]); io.fx = wg.bcast(rs[1]);
+        io.k = (int)wg.bcast(rs[2]); io.end = (int)wg.bcast(rs[3]); io.bound = (int)wg.bcast(rs[4]); io.budget = budget;
+        double f = 0.0;
+        int kk = 0;
+        const int ret = lbfgs<true>(f, kk, &io);
+        int accepted = 0, conv = 0;
+        if (evals > 0) refreshResiduals();
+        if (finish && ret != LBFGS_RUNNING_HOOK) {
+            accepted = (ret == LBFGS_CONVERGENCE || ret == LBFGS_CANCELED || ret == LBFGS_STOP || ret == LBFGSERR_MAXIMUMITERATION || ret == LBFGSERR_MAXIMUMLINESEARCH) ? 1 : 0;
+            if (accepted) { updateDualVars(); conv = judgeConvergence() ? 1 : 0; }
+        }
+        wg.pfor(n + MAX_PAST, [&](int t) { if (t < n) { gx[t] = x[t]; gg[t] = g[t]; gd[t] = d[t]; } else rs[8 + t - n] = pf[t - n]; });
+        wg.pfor(1, [&](int) {
+            rs[0] = io.step; rs[1] = io.fx; rs[2] = io.k; rs[3] = io.end; rs[4] = io.bound; rs[5] = ret; rs[6] = accepted; rs[7] = conv;
+            st.f = io.fx; st.last_lbfgs_ret = ret; st.lbfgs_iters = io.k;
+        });
+        storeTrajectory(st);
     }
 
     // diagnostic: shader-clock ticks per call of the phases of one evaluation (averaged over `reps`), written to st.cyc[0..7]

@@ -395,8 +395,9 @@ struct DevWG {
     }
 };
 
-// MODE 0: one (or `repeat`) objective evaluation(s)   1: reset + initScaling   2: ALM / L-BFGS solve   3: post-solve report
-// 4: initScaling only (test hook, keeps the resident duals).  A compile-time MODE gives each phase its own register budget.
+// MODE 0: one (or `repeat`) objective evaluation(s)   1: reset + initScaling   2: ALM / L-BFGS solve (repeat > 0: at most that many ALM passes)
+// 3: post-solve report   4: initScaling only (test hook, keeps the resident duals)   5: phase microbenchmark
+// 7: continue the L-BFGS loop from a host-given state (test hook; repeat = 2 * budget + finish_pass).  A compile-time MODE gives each phase its own register budget.
 template <int NT, int WPS, int MODE>
 __global__ __launch_bounds__(NT, WPS) void uph_solver_kernel(GridDev grid, OptParams P, BatchDev bd, int repeat) {
     extern __shared__ double lds[];
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(NT, WPS) void uph_solver_kernel(GridDev grid, OptPa
     TrajState& st = bd.state[b];
     if (MODE == 0) sol.evalOnly(st, repeat);
     else if (MODE == 1) sol.prepare(st);
-    else if (MODE == 2) sol.optimize(st);
+    else if (MODE == 2) sol.optimize(st, repeat);
+    else if (MODE == 7) sol.resumeHook(st, repeat >> 1, repeat & 1);
     else if (MODE == 3) sol.report(st);
     else if (MODE == 5) sol.microbench(st, repeat);
     else sol.scalingOnly(st);
@@ -476,7 +478,7 @@ struct uph_ctx {
     int lanes_forced = 0;                   // 0 = choose from the batch size
     int wps = 1;                            // workgroups of 256 lanes per CU the kernel is compiled for (1 or 2)
     int wps_forced = 0;                     // experiment knob: register-capped (2) or uncapped (1) build regardless of batch size
-    DevBuf d_thomas;
+    DevBuf d_thomas, d_rsd, d_rs;
     DevBuf d_desc, d_state, d_x, d_x0, d_gout, d_dual, d_res, d_scl, d_cxy, d_cyaw, d_hist, d_report, d_order, d_trace;
     int trace_cap = 0;
     std::vector<TrajState> state_host;
@@ -510,6 +512,7 @@ static BatchDev makeBatchDev(uph_ctx* c) {
     bd.trace_cap = c->trace_cap;
     bd.order = c->d_order.as<int>();
     bd.thomas = c->d_thomas.as<double>();
+    bd.rs_d = c->d_rsd.as<double>(); bd.rs = c->d_rs.as<double>();
     return bd;
 }
 
@@ -567,7 +570,12 @@ static int launchSolver(uph_ctx* c, int mode, int repeat) {
         else if (mode == 5) UPH_LAUNCH(NTL, WPS, 5);                                                                                 \
         else UPH_LAUNCH(NTL, WPS, 4);                                                                                                \
     } while (0)
-    if (c->lanes == 64 && c->wps_forced == 2) UPH_LAUNCH_MODE(64, 2);
+    if (mode == 7) {
+        if (c->lanes == 128) UPH_LAUNCH(128, 2, 7);
+        else if (c->lanes == 256) UPH_LAUNCH(256, 1, 7);
+        else { setError("the L-BFGS resume hook is built for 128 and 256 lanes"); return UPH_ERR_INVALID; }
+    }
+    else if (c->lanes == 64 && c->wps_forced == 2) UPH_LAUNCH_MODE(64, 2);
     else if (c->lanes == 64) UPH_LAUNCH_MODE(64, 1);
     else if (c->lanes == 128) UPH_LAUNCH_MODE(128, 2);
     else if (c->wps == 2 && mode == 2 && c->lds_bytes <= 80 * 1024) UPH_LAUNCH(256, 2, 2);
@@ -634,7 +642,7 @@ void uph_ctx_destroy(uph_ctx* c) {
     hipSetDevice(c->device);             // not via c->map: the map may already have been destroyed by the caller
     for (void* p : c->op_allocs) hipFree(p);
     DevBuf* bufs[] = {&c->d_ops, &c->d_desc, &c->d_state, &c->d_x, &c->d_gout, &c->d_dual, &c->d_res, &c->d_scl, &c->d_cxy, &c->d_cyaw,
-                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas};
+                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas, &c->d_rsd, &c->d_rs};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -782,7 +790,7 @@ int uph_batch_solve(uph_ctx* c) {
     int r = launchSolver(c, 1, 1);          // reset + initScaling (alm_traj_opt.cpp:193-203, 231-232)
     if (r != UPH_OK) return r;
     c->last_prepare_ms = c->last_ms;
-    r = launchSolver(c, 2, 1);              // ALM loop (alm_traj_opt.cpp:234-271)
+    r = launchSolver(c, 2, 0);              // ALM loop (alm_traj_opt.cpp:234-271)
     if (r != UPH_OK) return r;
     r = refreshStates(c);
     if (r != UPH_OK) return r;
@@ -929,6 +937,104 @@ int uph_report_batch(uph_ctx* c, double* out7) {
     int r = launchSolver(c, 3, 1);
     if (r != UPH_OK) return r;
     HIPCHK(hipMemcpy(out7, c->d_report.p, 8 * 7 * c->B, hipMemcpyDeviceToHost));
+    return UPH_OK;
+}
+
+// ---- test hooks of the teacher-forced late-state tests -------------------------------------------------------------------------
+static void collectSolveStats(uph_ctx* c) {
+    c->last_evals = c->last_sample_evals = c->last_iters = c->last_hist_bytes = 0;
+    for (int b = 0; b < c->B; b++) {
+        const TrajState& s = c->state_host[b];
+        c->last_evals += s.evals;
+        c->last_sample_evals += (int64_t)s.evals * c->desc[b].S;
+        c->last_iters += s.lbfgs_iters;
+        c->last_hist_bytes += s.hist_reads * 8;
+    }
+}
+int uph_batch_set_x(uph_ctx* c, const double* x_packed) {
+    if (!c || c->B <= 0 || !x_packed) { setError("uph_batch_set_x: bad arguments"); return UPH_ERR_INVALID; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->d_x.p, x_packed, 8 * c->sum_n, hipMemcpyHostToDevice));
+    return UPH_OK;
+}
+// the ALM loop of optimizeSE2Traj (alm_traj_opt.cpp:234-271) from the RESIDENT x, duals, scales and rho -- no reset, no initScaling --
+// for at most max_passes passes (0 = until it ends); a solve stopped by the cap reports ret_code 3
+int uph_batch_alm_passes(uph_ctx* c, int32_t max_passes) {
+    if (!c || c->B <= 0 || max_passes < 0) { setError("uph_batch_alm_passes: bad arguments"); return UPH_ERR_INVALID; }
+    int r = launchSolver(c, 2, max_passes);
+    if (r != UPH_OK) return r;
+    r = refreshStates(c);
+    if (r != UPH_OK) return r;
+    collectSolveStats(c);
+    return UPH_OK;
+}
+// L-BFGS state at the top of the iteration loop (lbfgs.hpp:555), per trajectory: g, d packed like x; pf [B][UPH_MAX_PAST]; the history
+// as the reference holds it -- lm_s / lm_y column j of trajectory b at hist[off_b + j*n] with off_b = mem * sum_{b' < b} n_b', lm_ys
+// [B][mem] --; scal5 [B][5] = step, fx, k, end, bound.  x is the resident x (uph_batch_set_x).
+int uph_batch_set_lbfgs_state(uph_ctx* c, const double* g, const double* d, const double* pf, const double* lm_s, const double* lm_y, const double* lm_ys, const double* scal5) {
+    if (!c || c->B <= 0 || !g || !d || !pf || !lm_s || !lm_y || !lm_ys || !scal5) { setError("uph_batch_set_lbfgs_state: bad arguments"); return UPH_ERR_INVALID; }
+    HIPCHK(hipSetDevice(c->device));
+    const int mem = c->P.mem_size;
+    if (c->d_rsd.ensure(8 * c->sum_n) || c->d_rs.ensure(8 * 24 * (size_t)c->B)) return UPH_ERR_HIP;
+    std::vector<double> hist((size_t)c->sum_hist, 0.0), rs((size_t)24 * c->B, 0.0);
+    int64_t off = 0;
+    for (int b = 0; b < c->B; b++) {
+        const TrajDesc& t = c->desc[b];
+        const int rowd = histRowDoubles(t.n), np = 64 * histNQ(t.n);
+        for (int j = 0; j < mem; j++) {
+            double* row = hist.data() + t.off_hist + (size_t)j * rowd;
+            const double ys = lm_ys[(size_t)b * mem + j];
+            row[0] = ys; row[1] = 1.0 / ys;
+            std::memcpy(row + 2, lm_s + off + (size_t)j * t.n, 8 * t.n);
+            std::memcpy(row + 2 + np, lm_y + off + (size_t)j * t.n, 8 * t.n);
+        }
+        off += (int64_t)mem * t.n;
+        for (int q = 0; q < 5; q++) rs[(size_t)24 * b + q] = scal5[5 * b + q];
+        for (int q = 0; q < UPH_MAX_PAST; q++) rs[(size_t)24 * b + 8 + q] = pf[(size_t)b * UPH_MAX_PAST + q];
+    }
+    HIPCHK(hipMemcpy(c->d_hist.p, hist.data(), 8 * c->sum_hist, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_rs.p, rs.data(), 8 * rs.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_gout.p, g, 8 * c->sum_n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_rsd.p, d, 8 * c->sum_n, hipMemcpyHostToDevice));
+    return UPH_OK;
+}
+// continue every trajectory's L-BFGS loop from the state set above for at most `budget` iterations (budget < 0: until it ends);
+// finish_pass != 0: when the loop ends by itself, the ALM's reaction follows (accepted code -> updateDualVars + judgeConvergence)
+int uph_batch_lbfgs_resume(uph_ctx* c, int32_t budget, int32_t finish_pass) {
+    if (!c || c->B <= 0 || !c->d_rs.p) { setError("uph_batch_lbfgs_resume: no state set"); return UPH_ERR_INVALID; }
+    const int bud = budget < 0 ? (1 << 28) : budget;
+    int r = launchSolver(c, 7, 2 * bud + (finish_pass ? 1 : 0));
+    if (r != UPH_OK) return r;
+    r = refreshStates(c);
+    if (r != UPH_OK) return r;
+    collectSolveStats(c);
+    return UPH_OK;
+}
+// the state after uph_batch_lbfgs_resume, same layout; scal8 [B][8] = step, fx, k, end, bound, L-BFGS code (999 = budget ran out),
+// accepted, converged.  x / hx / gx / duals / rho through uph_batch_download.
+int uph_batch_get_lbfgs_state(uph_ctx* c, double* g, double* d, double* pf, double* lm_s, double* lm_y, double* lm_ys, double* scal8) {
+    if (!c || c->B <= 0 || !c->d_rs.p) { setError("uph_batch_get_lbfgs_state: no state set"); return UPH_ERR_INVALID; }
+    HIPCHK(hipSetDevice(c->device));
+    const int mem = c->P.mem_size;
+    std::vector<double> hist((size_t)c->sum_hist), rs((size_t)24 * c->B);
+    HIPCHK(hipMemcpy(hist.data(), c->d_hist.p, 8 * c->sum_hist, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rs.data(), c->d_rs.p, 8 * rs.size(), hipMemcpyDeviceToHost));
+    if (g) HIPCHK(hipMemcpy(g, c->d_gout.p, 8 * c->sum_n, hipMemcpyDeviceToHost));
+    if (d) HIPCHK(hipMemcpy(d, c->d_rsd.p, 8 * c->sum_n, hipMemcpyDeviceToHost));
+    int64_t off = 0;
+    for (int b = 0; b < c->B; b++) {
+        const TrajDesc& t = c->desc[b];
+        const int rowd = histRowDoubles(t.n), np = 64 * histNQ(t.n);
+        for (int j = 0; j < mem; j++) {
+            const double* row = hist.data() + t.off_hist + (size_t)j * rowd;
+            if (lm_ys) lm_ys[(size_t)b * mem + j] = row[0];
+            if (lm_s) std::memcpy(lm_s + off + (size_t)j * t.n, row + 2, 8 * t.n);
+            if (lm_y) std::memcpy(lm_y + off + (size_t)j * t.n, row + 2 + np, 8 * t.n);
+        }
+        off += (int64_t)mem * t.n;
+        if (scal8) for (int q = 0; q < 8; q++) scal8[8 * b + q] = rs[(size_t)24 * b + q];
+        if (pf) for (int q = 0; q < UPH_MAX_PAST; q++) pf[(size_t)b * UPH_MAX_PAST + q] = rs[(size_t)24 * b + 8 + q];
+    }
     return UPH_OK;
 }
 

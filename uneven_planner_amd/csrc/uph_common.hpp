@@ -142,6 +142,8 @@ struct BatchDev {
     double* cxy;        // [sum 12 Nxy]
     double* cyaw;       // [sum 6 Nyaw]
     double* hist;       // L-BFGS history, per trajectory mem rows of histRowDoubles(n): [y.s, 1/(y.s) | s padded to 64 NQ | y padded]  (pads stay zero)
+    double* rs_d;       // test hook (teacher-forced L-BFGS state): direction vectors [sum n]
+    double* rs;         // ... and 24 scalars per trajectory (Solver::resumeHook)
     double* report;     // [B*7]
     double* trace;      // optional [B*trace_cap] diagnostic cost trace (nullptr = off)
     int trace_cap;
