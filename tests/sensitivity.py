@@ -37,3 +37,21 @@ def spread(res_a, res_b, key_cost_a="cost", key_cost_b="cost"):
     return dict(x_median=float(np.median(dx)), x_p90=float(np.percentile(dx, 90)), x_max=float(dx.max()), x_le_1e4=float((dx <= 1e-4).mean()),
                 c_median=float(np.median(dc)), c_p90=float(np.percentile(dc, 90)), c_max=float(dc.max()), c_le_1e4=float((dc <= 1e-4).mean()),
                 same_ret=same)
+
+
+BUCKET_EDGES = [0, 40, 80, 120, 180, 260, 400, 100000]
+
+
+def bucket_table(ref, other, edges=BUCKET_EDGES):
+    """agreement of `other` with `ref` (final way-points / cost, relative, infinity norm), bucketed by ref's total L-BFGS iterations"""
+    k = np.array([r["lbfgs_iters"] for r in ref])
+    dx = np.array([np.abs(a["x"] - b["x"]).max() / np.abs(b["x"]).max() for a, b in zip(other, ref)])
+    dc = np.array([abs(a["cost"] - b["cost"]) / abs(b["cost"]) for a, b in zip(other, ref)])
+    rows = []
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        m = (k >= lo) & (k < hi)
+        if m.sum() == 0:
+            continue
+        rows.append(dict(lo=lo, hi=hi, n=int(m.sum()), x_le_1e4=float((dx[m] <= 1e-4).mean()), c_le_1e4=float((dc[m] <= 1e-4).mean()),
+                         x_median=float(np.median(dx[m])), x_max=float(dx[m].max())))
+    return rows

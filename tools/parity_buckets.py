@@ -1,0 +1,55 @@
+"""Final-trajectory parity, bucketed by the length of the solve.
+
+For N random hill-cloud problems and a few parameter sets (the shipped run_hill.yaml values and two that cap the L-BFGS iterations
+per ALM pass, which yields short solves), three solvers run on identical inputs: the CPU oracle, the same oracle rebuilt with FMA
+contraction (the reference's own reproducibility floor: ~1 ulp per operation, nothing else changed) and the device.  Rows = buckets
+of the oracle's total L-BFGS iteration count; columns = fraction of problems whose final way-points / cost agree with the oracle
+to 1e-4 (relative, infinity norm) and the median deviation.  usage: python tools/parity_buckets.py [N] [out.json]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import sensitivity                          # noqa: E402
+import uneven_planner_amd as U              # noqa: E402
+from oracle import oracle_py as O           # noqa: E402
+from uneven_planner_amd import scenes       # noqa: E402
+
+PARAM_SETS = [("run_hill.yaml", None), ("inner_max_iter=8", dict(inner_max_iter=8.0)), ("inner_max_iter=3", dict(inner_max_iter=3.0))]
+bucket_table = sensitivity.bucket_table
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    m = U.UnevenMap()
+    m.build(scenes.make_hill_cloud())
+    nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
+    probs = scenes.random_problems(N, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
+    og = O.OracleGrid()
+    og.set_cells(m.map_buffer)
+    report = {}
+    for tag, prm in PARAM_SETS:
+        ref = [O.OracleALM(og, prm).optimize(p) for p in probs]
+        fma = sensitivity.solve_with_fma_oracle(m.map_buffer, probs, prm)
+        opt = U.ALMTrajOpt(m, prm)
+        opt.set_lanes(128)
+        opt.set_rho(1.0)
+        dev = opt.optimize_batch(probs)
+        report[tag] = dict(device=bucket_table(ref, dev), floor=bucket_table(ref, fma),
+                           same_ret_device=float(np.mean([a["ret"] == b["ret"] for a, b in zip(dev, ref)])),
+                           same_ret_floor=float(np.mean([a["ret"] == b["ret"] for a, b in zip(fma, ref)])))
+        print("== %s   (same return code: device %.0f %%, floor %.0f %%)" % (tag, 100 * report[tag]["same_ret_device"], 100 * report[tag]["same_ret_floor"]))
+        print("  L-BFGS iterations    n | device: way-points<=1e-4  cost<=1e-4  median   max    | oracle(FMA): way-points<=1e-4  cost<=1e-4  median   max")
+        for d, f in zip(report[tag]["device"], report[tag]["floor"]):
+            print("  [%4d, %6d) %5d |        %5.0f %%          %5.0f %%   %.1e %.1e |             %5.0f %%          %5.0f %%   %.1e %.1e" % (
+                d["lo"], d["hi"], d["n"], 100 * d["x_le_1e4"], 100 * d["c_le_1e4"], d["x_median"], d["x_max"],
+                100 * f["x_le_1e4"], 100 * f["c_le_1e4"], f["x_median"], f["x_max"]))
+    if len(sys.argv) > 2:
+        json.dump(report, open(sys.argv[2], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
