@@ -17,6 +17,8 @@
  *   uph_map_get_cells       -> fills UnevenMap::map_buffer / c_buffer / occ_buffer / occ_r2_buffer
  *                              uneven_map/include/uneven_map/uneven_map.h:91-94, occupancy rule uneven_map.cpp:170-179
  *   uph_terrain_query       <- UnevenMap::getAllWithGrad  uneven_map.h:318-377 (device-side twin, exposed for parity tests)
+ *   uph_terrain_pose_query  <- UnevenMap::getTerrainPos  uneven_map.h:203-218 (batched)
+ *   uph_map_filter_cloud    <- pcl::CropBox + pcl::VoxelGrid as UnevenMap::init applies them  uneven_map.cpp:133-143
  *   uph_frontend_query      <- UnevenMap::getTerrainSig / isOccupancy / isOccupancyXY  uneven_map.h:389-396, 471-498 (batched)
  *   uph_eval_batch          <- innerCallback  alm_traj_opt.cpp:280-347 (one objective+gradient evaluation; test/bench hook)
  *   uph_init_scaling_batch  <- ALMTrajOpt::initScaling  alm_traj_opt.cpp:349-661 (test hook)
@@ -136,7 +138,14 @@ int uph_terrain_query(uph_map* m, const double* pos, int32_t n, double* values7,
  * occ[n] = isOccupancy(pos), occ_xy[n] = isOccupancyXY(pos) (uneven_map.h:471-498; -1 outside).  Any output may be NULL. */
 int uph_frontend_query(uph_map* m, const double* pos, int32_t n, double* sigma, int32_t* occ, int32_t* occ_xy);
 /* kernel milliseconds of the last uph_frontend_query (HIP events) */
+/* batched UnevenMap::getTerrainPos (uneven_map.h:203-218) served from the device grid: pose12[n][12] = rotation matrix column-major
+ * (x_b, y_b, z_b), then the position (x, y, interpolated z) */
+int uph_terrain_pose_query(uph_map* m, const double* pos, int32_t n, double* pose12);
 int uph_frontend_query_ms(uph_map* m, double* kernel_ms);
+/* the cloud uph_map_build fits planes to: UnevenMap::init's pcl::CropBox [-10,10]^2 x [-0.01,5] followed by pcl::VoxelGrid with a 1 cm
+ * leaf (uneven_map.cpp:133-143), applied to xyz (n points).  out_xyz takes at most cap points (NULL: count only); returns the
+ * number of filtered points, < 0 on error.  Host function: no device needed. */
+int64_t uph_map_filter_cloud(const float* xyz, int64_t n, float* out_xyz, int64_t cap);
 /* last uph_map_build timing: kernel milliseconds (HIP events) and number of cell-iterations processed */
 int uph_map_build_stats(uph_map* m, double* kernel_ms, int64_t* cell_iters, int64_t* cloud_points);
 

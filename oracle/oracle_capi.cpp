@@ -324,6 +324,15 @@ int orc_alm_get_trace(void* h, double* out, int cap) {
     for (int i = 0; i < n; i++) out[i] = t[i];
     return (int)t.size();
 }
+// install a trajectory (coefficients in the reference's internal layout, uniform piece durations) without generating it: lets the
+// post-solve report be evaluated on coefficients that came from elsewhere (the device's stored trajectory)
+void orc_alm_set_coeffs(void* h, const double* c_xy, const double* c_yaw, double T_xy, double T_yaw) {
+    AlmTrajOpt& a = ((OrcAlm*)h)->opt;
+    std::memcpy(a.minco.pos.c.data(), c_xy, 8 * a.minco.pos.c.size());
+    std::memcpy(a.minco.yaw.c.data(), c_yaw, 8 * a.minco.yaw.c.size());
+    std::fill(a.minco.pos.T1.begin(), a.minco.pos.T1.end(), T_xy);
+    std::fill(a.minco.yaw.T1.begin(), a.minco.yaw.T1.end(), T_yaw);
+}
 void orc_alm_report(void* h, double* out7) { ((OrcAlm*)h)->opt.report(out7); }
 
 // ---------------- map build

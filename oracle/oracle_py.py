@@ -80,6 +80,7 @@ def lib():
         L.orc_alm_optimize.restype = i
         L.orc_alm_optimize.argtypes = [vp, dp, dp, dp, i, dp, dp, dp, i, d, dp, dp]
         L.orc_alm_report.argtypes = [vp, dp]
+        L.orc_alm_set_coeffs.argtypes = [vp, dp, dp, d, d]
         L.orc_alm_set_capture.argtypes = [vp, i, i, i]
         L.orc_alm_get_iter_log.restype = i
         L.orc_alm_get_iter_log.argtypes = [vp, ip, i]
@@ -343,6 +344,10 @@ class OracleALM:
         buf = np.zeros(cap)
         n = self.L.orc_alm_get_trace(self.h, _dp(buf), cap)
         return buf[:min(n, cap)]
+
+    def set_coeffs(self, c_xy, c_yaw, T_xy, T_yaw):
+        """install a trajectory given by its coefficients (after setup()); report() then evaluates exactly that trajectory"""
+        self.L.orc_alm_set_coeffs(self.h, _dp(_f64(c_xy)), _dp(_f64(c_yaw)), float(T_xy), float(T_yaw))
 
     def report(self):
         out = np.zeros(7)

@@ -1,5 +1,6 @@
-"""CPU tier, world_size 2 over gloo: the N > 1 paths -- (a) the x-slab sharded map build + one all-gather (SURVEY.md 8e;
-RCCL on the GPUs, gloo here) reproduces the single-process build, with the CPU oracle standing in for the device kernel;
+"""CPU tier, world_size 2 and 3 over gloo: the N > 1 paths -- (a) the x-slab sharded map build + one all-gather (SURVEY.md 8e;
+RCCL on the GPUs, gloo here) through the PRODUCT's slab rule and exchange (uneven_map.slab_bounds / gather_slabs) reproduces the
+single-process build, with the CPU oracle standing in for the device kernel;
 (b) the batch sharding of bench.py gives every rank a disjoint, reproducible set of problems and a max-over-ranks time."""
 import os
 import sys
@@ -22,16 +23,17 @@ def _worker(rank, world, port, out_dir):
     from uneven_planner_amd import scenes
     xyz = scenes.make_hill_cloud(n_side=100, half=1.5)
     mp_ = dict(map_size_x=2.0, map_size_y=2.0)
+    from uneven_planner_amd.uneven_map import gather_slabs, slab_bounds      # the PRODUCT's slab rule and exchange ...
     g = O.OracleGrid(size_x=2.0, size_y=2.0)
     nx, ny, nyaw = g.dims
-    per = nx // world
-    x0, x1 = rank * per, (rank + 1) * per             # same slab rule as UnevenMap.build_sharded
+    row = ny * nyaw * 4
+    per, x0, x1 = slab_bounds(nx, rank, world)
     b = O.OracleMapBuilder(xyz=xyz)
-    b.construct(g, map_params=mp_, x0=x0, x1=x1, do_occ=False)
+    b.construct(g, map_params=mp_, x0=x0, x1=x1, do_occ=False)         # ... around the oracle's fit instead of the device kernel
     cells, _ = g.get_cells()
-    slab = torch.from_numpy(cells.reshape(nx, -1)[x0:x1].copy().ravel())
-    full = torch.empty(nx * ny * nyaw * 4, dtype=torch.float64)
-    dist.all_gather_into_tensor(full, slab)
+    slab = torch.zeros(per * row, dtype=torch.float64)
+    slab[:(x1 - x0) * row] = torch.from_numpy(cells.reshape(nx, -1)[x0:x1].copy().ravel())
+    full = gather_slabs(slab, nx, row, world, lambda f, s_: dist.all_gather_into_tensor(f, s_))
     # batch sharding: seeds 1000 + rank*B + i
     B = 3
     probs = scenes.random_problems(B, seed0=1000 + rank * B)
@@ -46,8 +48,8 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_map_build_and_batch_split(tmp_path, oracle):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])       # 3: nx = 40 does not divide -> the padded last slab
+def test_sharded_map_build_and_batch_split(tmp_path, oracle, world):
     port = 29500 + (os.getpid() % 500)
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     z = np.load(str(tmp_path / "r0.npz"))
@@ -59,7 +61,7 @@ def test_sharded_map_build_and_batch_split(tmp_path, oracle):
     cells, _ = g.get_cells()
     assert np.array_equal(z["full"].reshape(-1, 4), cells)          # slab build + all-gather == single build, bit for bit
     keys = z["keys"]
-    assert keys.shape == (2, 3) and len(set(keys.ravel().tolist())) == 6   # disjoint problem sets
+    assert keys.shape == (world, 3) and len(set(keys.ravel().tolist())) == 3 * world   # disjoint problem sets
     ref = [p["total_time"] for p in scenes.random_problems(3, seed0=1003)]
     assert np.allclose(keys[1], ref)
-    assert abs(float(z["tmax"][0]) - 0.2) < 1e-12                          # max over ranks
+    assert abs(float(z["tmax"][0]) - 0.1 * world) < 1e-12                  # max over ranks

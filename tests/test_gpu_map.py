@@ -91,3 +91,81 @@ def test_frontend_queries_match_the_host_mirror(oracle):
     v, _ = og.all_with_grad(pos[inside])
     assert np.abs(v[:, 6] - sg[inside]).max() < 1e-12          # sigma of getAllWithGrad == getTerrainSig where both are defined
     assert (oc == -1).sum() > 0 and (oc == 0).sum() > 0 and (oxy >= 0).sum() > 0
+
+
+def test_rebuild_starts_from_fresh_cells():
+    """constructMap starts every cell from RXS2() with c = 1 (uneven_map.cpp:117-119): a second build, or a build after set_cells,
+    must give the grid of the first build -- not extra refinement iterations from whatever the slab held"""
+    import uneven_planner_amd as U
+    from uneven_planner_amd import scenes
+    xyz = scenes.make_hill_cloud(n_side=160, half=3.0)
+    m = U.UnevenMap()
+    m.build(xyz, x0=90, x1=110)
+    first = m.map_buffer.copy()
+    m.build(xyz, x0=90, x1=110)
+    assert np.array_equal(m.map_buffer, first)
+    m.set_cells(np.random.default_rng(0).uniform(-0.3, 0.3, size=first.shape))
+    m.build(xyz, x0=90, x1=110)
+    nyz = 200 * 64
+    assert np.array_equal(m.map_buffer[90 * nyz:110 * nyz], first[90 * nyz:110 * nyz])
+
+
+def test_large_ellipsoid_staging_window(oracle):
+    """ellipsoid axes beyond the default 0.2 m: the LDS staging window follows the search radius (0.12 + largest axis); a too small
+    window would silently drop points and change the fits"""
+    import uneven_planner_amd as U
+    from uneven_planner_amd import scenes
+    xyz = scenes.make_hill_cloud(n_side=200, half=2.5)
+    prm = dict(ellipsoid_x=0.45, ellipsoid_y=0.25, ellipsoid_z=0.2)
+    m = U.UnevenMap(prm)
+    m.build(xyz, x0=98, x1=102)
+    g = oracle.OracleGrid()
+    b = oracle.OracleMapBuilder(xyz=xyz)
+    b.construct(g, map_params=prm, x0=98, x1=102, do_occ=False)
+    co, _ = g.get_cells()
+    sl = slice(98 * 200 * 64, 102 * 200 * 64)
+    d, bad = _compare(m.map_buffer[sl], co[sl])
+    assert bad < 1e-3 and np.median(d) < 1e-12, (bad, d.max())
+
+
+def test_init_with_map_file_cache(tmp_path):
+    """UnevenMap::init (uneven_map.cpp:166-167): build + write the `.map` cache when it is missing, read it when present; the CSV keeps 6
+    significant digits, the binary side-car is bit exact"""
+    import uneven_planner_amd as U
+    from uneven_planner_amd import scenes
+    xyz = scenes.make_hill_cloud(n_side=120, half=2.0)
+    prm = dict(map_size_x=4.0, map_size_y=4.0)
+    path = str(tmp_path / "hill.map")
+    a = U.UnevenMap(prm).init(xyz=xyz, map_file=path)              # builds, writes hill.map and hill.map.bin
+    built = a.map_buffer.copy()
+    b = U.UnevenMap(prm).init(map_file=path)                       # reads the side-car
+    assert np.array_equal(b.map_buffer, built) and np.array_equal(b.occ_buffer, a.occ_buffer)
+    import os
+    os.remove(path + ".bin")
+    c = U.UnevenMap(prm).init(map_file=path)                       # reads the CSV like constructMapInput
+    assert np.abs(c.map_buffer - built).max() < 1e-5 * max(1.0, np.abs(built).max()) and not np.array_equal(c.map_buffer, built)
+    pos = np.array([[0.3, -0.2, 0.5]])
+    assert np.abs(c.getAllWithGrad(pos)[0] - a.getAllWithGrad(pos)[0]).max() < 1e-4
+
+
+def test_terrain_pose_query_matches_the_oracle_terrain(oracle, analytic_cells):
+    """batched getTerrainPos (uneven_map.h:203-218) served from the device grid"""
+    import uneven_planner_amd as U
+    m = U.UnevenMap()
+    m.set_cells(analytic_cells)
+    og = oracle.OracleGrid()
+    og.set_cells(analytic_cells)
+    rng = np.random.default_rng(5)
+    n = 5000
+    pos = np.column_stack([rng.uniform(-5.2, 5.2, n), rng.uniform(-5.2, 5.2, n), rng.uniform(-np.pi, np.pi, n)])
+    R, p = m.getTerrainPosBatch(pos)
+    t = og.terrain(pos)                                            # z, sigma, zb.x, zb.y by the oracle's getTerrain
+    zb = np.column_stack([t[:, 2], t[:, 3], np.sqrt(1.0 - t[:, 2] ** 2 - t[:, 3] ** 2)])
+    xyaw = np.column_stack([np.cos(pos[:, 2]), np.sin(pos[:, 2]), np.zeros(n)])
+    yb = np.cross(zb, xyaw)
+    yb /= np.linalg.norm(yb, axis=1)[:, None]
+    xb = np.cross(yb, zb)
+    assert np.abs(R[:, :, 2] - zb).max() < 1e-12 and np.abs(R[:, :, 1] - yb).max() < 1e-12 and np.abs(R[:, :, 0] - xb).max() < 1e-12
+    assert np.abs(p[:, 2] - t[:, 0]).max() < 1e-12 and np.array_equal(p[:, :2], pos[:, :2])
+    Rh, ph = m.getTerrainPos(pos[7])                               # the host mirror agrees
+    assert np.abs(Rh - R[7]).max() < 1e-12 and np.abs(ph - p[7]).max() < 1e-12

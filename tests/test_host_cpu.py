@@ -85,3 +85,58 @@ def test_host_grid_view_matches_oracle(oracle, oracle_grid, analytic_cells, tmp_
     small.write_map_file(path)
     back = HostGridView.read_map_file(path, map_size_x=0.5, map_size_y=0.5)
     assert 0 < np.abs(back.cells - small.cells).max() < 1e-5
+
+
+# ---- M1: crop box + voxel grid of the PRODUCT's host path against the oracle's restatement of PCL (uneven_map.cpp:133-143)
+def test_product_cloud_filter_merges_and_rejects_like_the_oracle(oracle):
+    import uneven_planner_amd as U
+    rng = np.random.default_rng(17)
+    base = rng.uniform(-3.0, 3.0, size=(4000, 3)).astype(np.float32)
+    base[:, 2] = np.abs(base[:, 2]) * 0.5
+    dup = base[:1500] + rng.uniform(-0.004, 0.004, size=(1500, 3)).astype(np.float32)       # several points per 1 cm voxel
+    trip = base[:400] + rng.uniform(-0.003, 0.003, size=(400, 3)).astype(np.float32)
+    outside = np.array([[10.5, 0, 1], [0, -10.2, 1], [0, 0, 5.5], [0, 0, -0.02], [-11, -11, 0], [np.nan, 0, 0], [0, np.inf, 0]], dtype=np.float32)
+    edge = np.array([[10.0, 10.0, 5.0], [-10.0, -10.0, -0.01]], dtype=np.float32)             # on the faces of the crop box: kept (inclusive)
+    cloud = np.vstack([base, dup, outside, trip, edge])
+    cloud = cloud[rng.permutation(cloud.shape[0])]
+    got = U.UnevenMap.filter_cloud(cloud)
+    want = oracle.OracleMapBuilder(xyz=cloud).cloud()
+    assert want.shape[0] < cloud.shape[0] - 500                  # the filter really merged (several points per voxel) and rejected
+    assert got.shape == want.shape and np.array_equal(got, want)     # bit for bit, same order (leaf-index order)
+
+
+def test_product_cloud_filter_on_a_cloud_without_merges(oracle):
+    import uneven_planner_amd as U
+    from uneven_planner_amd import scenes
+    xyz = scenes.make_hill_cloud(n_side=80, half=2.0)
+    assert np.array_equal(U.UnevenMap.filter_cloud(xyz), oracle.OracleMapBuilder(xyz=xyz).cloud())
+
+
+# ---- M5 / N3: `.map` CSV cache both ways between the product's host view and the oracle, and the bit-exact binary side-car
+def test_map_csv_cross_reads_and_binary_sidecar(tmp_path, oracle):
+    import ctypes as C
+    from uneven_planner_amd.host_map import HostGridView
+    rng = np.random.default_rng(3)
+    g = oracle.OracleGrid(size_x=1.0, size_y=1.0)
+    cells = np.column_stack([rng.normal(size=g.ncell), rng.uniform(0, 0.2, g.ncell), rng.uniform(-0.3, 0.3, g.ncell), rng.uniform(-0.3, 0.3, g.ncell)])
+    g.set_cells(cells)
+    L = oracle.lib()
+    # oracle writes (reference format: default ostream precision = 6 significant digits), product reads
+    p1 = str(tmp_path / "oracle.map")
+    assert L.orc_map_write_csv(g.h, p1.encode()) == 0
+    v = HostGridView.read_map_file(p1, 1.0, 1.0)
+    assert np.abs(v.cells.reshape(-1, 4) - cells).max() < 1e-5 * max(1.0, np.abs(cells).max())
+    # product writes, oracle reads: both must land on the same 6-digit values
+    p2 = str(tmp_path / "product.map")
+    HostGridView(cells, 1.0, 1.0).write_map_file(p2)
+    g2 = oracle.OracleGrid(size_x=1.0, size_y=1.0)
+    assert L.orc_map_read_csv(g2.h, p2.encode()) == 0
+    assert np.array_equal(g2.get_cells()[0], v.cells.reshape(-1, 4))            # identical text -> identical doubles (incl. the reference's stold double rounding)
+    assert open(p1).read() == open(p2).read()                                  # the two writers produce the same file
+    # binary side-car: bit-exact round trip, refuses a grid of another shape
+    p3 = str(tmp_path / "product.map.bin")
+    HostGridView(cells, 1.0, 1.0).write_map_binary(p3)
+    assert np.array_equal(HostGridView.read_map_binary(p3, 1.0, 1.0).cells.reshape(-1, 4), cells)
+    import pytest
+    with pytest.raises(ValueError):
+        HostGridView.read_map_binary(p3, 2.0, 1.0)

@@ -60,7 +60,9 @@ SYMBOLS = {
     "uph_map_import_cells_dev": (C.c_int, [_VP, _VP]),
     "uph_terrain_query": (C.c_int, [_VP, DP, _I32, DP, DP]),
     "uph_frontend_query": (C.c_int, [_VP, DP, _I32, DP, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "uph_terrain_pose_query": (C.c_int, [_VP, DP, _I32, DP]),
     "uph_frontend_query_ms": (C.c_int, [_VP, DP]),
+    "uph_map_filter_cloud": (_I64, [C.POINTER(C.c_float), _I64, C.POINTER(C.c_float), _I64]),
     "uph_map_build_stats": (C.c_int, [_VP, DP, C.POINTER(_I64), C.POINTER(_I64)]),
     "uph_ctx_create": (C.c_int, [_VP, C.POINTER(OptParams), C.POINTER(_VP)]),
     "uph_ctx_destroy": (None, [_VP]),

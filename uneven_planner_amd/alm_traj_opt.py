@@ -124,8 +124,10 @@ class ALMTrajOpt:
 
     def upload(self, probs):
         arr, keep = self._make_problems(probs)
+        self._B = 0
         _lib.check(self.L.uph_batch_upload(self.h, len(probs), arr), "uph_batch_upload")
         self._B = len(probs)
+        self._trace_cap_up = getattr(self, "_trace_cap", 0)
 
     def solve(self):
         """Kernel only (inputs already resident in HBM)."""
@@ -278,6 +280,6 @@ class ALMTrajOpt:
         self._trace_cap = int(cap)
 
     def get_trace(self):
-        out = np.zeros((self._B, self._trace_cap))
+        out = np.zeros((self._B, self._trace_cap_up))
         _lib.check(self.L.uph_ctx_get_trace(self.h, _dp(out)), "uph_ctx_get_trace")
         return out

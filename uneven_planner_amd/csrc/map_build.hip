@@ -41,6 +41,9 @@ struct uph_map {
     int64_t last_cell_iters = 0, last_cloud = 0;
 };
 
+UphDevTmp::~UphDevTmp() { if (p) hipFree(p); }
+UphEventTmp::~UphEventTmp() { if (e) hipEventDestroy((hipEvent_t)e); }
+
 int uphMapDevice(const uph_map* m) { return m->device; }
 GridDev uphMapGrid(const uph_map* m) { return m->g; }
 
@@ -122,7 +125,7 @@ __device__ int nearest2DGlobal(const CloudDev& cd, float qx, float qy, float* zo
 
 // one wave64 per (x,y) column of the slab [x0, x1)
 __global__ __launch_bounds__(64) void uph_map_build_kernel(GridDev g, CloudDev cd, double* __restrict__ cells, int x0, int x1, int iter_num,
-                                                           double ell_x, double ell_y, double ell_z, int lds_cap) {
+                                                           double ell_x, double ell_y, double ell_z, int lds_cap, int* __restrict__ overflow) {
     extern __shared__ float4 spts[];
     const int col = blockIdx.x;
     const int x = x0 + col / g.ny, y = col % g.ny;
@@ -155,15 +158,19 @@ __global__ __launch_bounds__(64) void uph_map_build_kernel(GridDev g, CloudDev c
             count += __popcll(mask);
         }
     }
-    if (count > lds_cap) count = lds_cap;      // cannot happen: lds_cap is the host-computed window maximum
+    if (count > lds_cap) {                     // the host sized the staging area for the largest window: report, never fit silently on a truncated disc
+        if (lane == 0) atomicExch(overflow, 1);
+        count = lds_cap;
+    }
     __syncthreads();
     const int npts = count;
     const double einv0 = 1.0 / ell_x, einv1 = 1.0 / ell_y, einv2 = 1.0 / ell_z;
     const float r2f = (float)box_r * (float)box_r;
     for (int yaw = lane; yaw < g.nyaw; yaw += 64) {
         const size_t addr = ((size_t)x * g.ny + y) * g.nyaw + yaw;
-        double cz = cells[addr * 4 + 0], csig = cells[addr * 4 + 1], czbx = cells[addr * 4 + 2], czby = cells[addr * 4 + 3];
-        double cc = sqrt(1.0 - czbx * czbx - czby * czby);           // c_buffer == getC() of the stored cell (:385,390; 1.0 for a fresh cell)
+        // constructMap starts every cell from a fresh RXS2() with c_buffer = 1 (uneven_map.cpp:117-119, 329-331), whatever an earlier
+        // build, set_cells or import left in the slab
+        double cz = 0.0, csig = 0.0, czbx = 0.0, czby = 0.0, cc = 1.0;
         const double yawc = (yaw + 0.5) * g.yaw_res + g.origin[2];
         const double cyw = cos(yawc), syw = sin(yawc);
         for (int iter = 0; iter < iter_num; iter++) {
@@ -347,6 +354,27 @@ __global__ void uph_frontend_kernel(GridDev g, const char* __restrict__ occ, con
     occxy_out[i] = in ? (int)occ2[(size_t)ix * g.ny + iy] : -1;
 }
 
+// UnevenMap::getTerrainPos (uneven_map.h:203-218): SE(3) pose on the terrain, one query per lane.  out[12] = R column-major
+// (x_b, y_b, z_b) then p
+__global__ void uph_pose_kernel(GridDev g, const double* __restrict__ pos, int n, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = pos[3 * i], y = pos[3 * i + 1], w = pos[3 * i + 2];
+    Corners c;
+    locate(g, x, y, w, c);
+    double z = 0.0, zx = 0.0, zy = 0.0;
+    if (c.inmap) { z = interpValue(g.z, c); zx = interpValue(g.zbx, c); zy = interpValue(g.zby, c); }
+    const double zz = sqrt(1.0 - zx * zx - zy * zy);                 // RXS2::getC
+    const double cw = cos(w), sw = sin(w);
+    double y0 = zy * 0.0 - zz * sw, y1 = zz * cw - zx * 0.0, y2 = zx * sw - zy * cw;      // zb x xyaw
+    const double yn = sqrt(y0 * y0 + y1 * y1 + y2 * y2);
+    y0 /= yn; y1 /= yn; y2 /= yn;
+    const double x0 = y1 * zz - y2 * zy, x1 = y2 * zx - y0 * zz, x2 = y0 * zy - y1 * zx; // yb x zb
+    double* o = out + 12 * (size_t)i;
+    o[0] = x0; o[1] = x1; o[2] = x2; o[3] = y0; o[4] = y1; o[5] = y2; o[6] = zx; o[7] = zy; o[8] = zz;
+    o[9] = x; o[10] = y; o[11] = z;
+}
+
 extern "C" {
 
 int uph_map_create(const uph_map_params* mp, int device, uph_map** out) {
@@ -474,7 +502,10 @@ int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x
             pts[cur[bucketOf(i)]++] = p;
         }
     }
-    // LDS capacity: the largest point count of any 7 x 7 bucket window (>= any staged disc)
+    // LDS capacity: the largest point count of any (2 hw + 1)^2 bucket window, hw from the staging radius the kernel uses
+    // (0.12 probe offset + largest ellipsoid axis + margin): covers every staged disc for whatever ellipsoid the parameters give
+    const double box_r = std::max(std::max(m->mp.ellipsoid_x, m->mp.ellipsoid_y), m->mp.ellipsoid_z);
+    const int hw = (int)std::ceil((0.12 + box_r + 1.0e-3) / bsize) + 1;
     int cap = 64;
     {
         std::vector<int64_t> ps((size_t)(bnx + 1) * (bny + 1), 0);
@@ -485,40 +516,52 @@ int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x
             }
         for (int ix = 0; ix < bnx; ix++)
             for (int iy = 0; iy < bny; iy++) {
-                const int xa = std::max(0, ix - 3), xb = std::min(bnx, ix + 4), ya = std::max(0, iy - 3), yb = std::min(bny, iy + 4);
+                const int xa = std::max(0, ix - hw), xb = std::min(bnx, ix + hw + 1), ya = std::max(0, iy - hw), yb = std::min(bny, iy + hw + 1);
                 const int64_t cnt = ps[(size_t)xb * (bny + 1) + yb] - ps[(size_t)xa * (bny + 1) + yb] - ps[(size_t)xb * (bny + 1) + ya] + ps[(size_t)xa * (bny + 1) + ya];
                 cap = std::max<int64_t>(cap, cnt);
             }
     }
     const size_t lds_bytes = (size_t)cap * sizeof(float4);
     if (lds_bytes > 150 * 1024) { setError("uph_map_build: cloud too dense for the LDS staging window"); return UPH_ERR_LIMIT; }
-    float4* d_pts = nullptr;
-    int* d_bstart = nullptr;
-    HIPCHK(hipMalloc((void**)&d_pts, np * sizeof(float4)));
-    HIPCHK(hipMalloc((void**)&d_bstart, bstart.size() * sizeof(int)));
-    HIPCHK(hipMemcpy(d_pts, pts.data(), np * sizeof(float4), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice));
+    UphDevTmp t_pts, t_bstart, t_ovf;
+    HIPCHK(hipMalloc(&t_pts.p, np * sizeof(float4)));
+    HIPCHK(hipMalloc(&t_bstart.p, bstart.size() * sizeof(int)));
+    HIPCHK(hipMalloc(&t_ovf.p, sizeof(int)));
+    HIPCHK(hipMemset(t_ovf.p, 0, sizeof(int)));
+    HIPCHK(hipMemcpy(t_pts.p, pts.data(), np * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t_bstart.p, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice));
     CloudDev cd;
-    cd.pts = d_pts; cd.bstart = d_bstart; cd.bx0 = bx0; cd.by0 = by0; cd.bsize = bsize; cd.bnx = bnx; cd.bny = bny; cd.npts = (int)np;
+    cd.pts = t_pts.as<float4>(); cd.bstart = t_bstart.as<int>(); cd.bx0 = bx0; cd.by0 = by0; cd.bsize = bsize; cd.bnx = bnx; cd.bny = bny; cd.npts = (int)np;
     HIPCHK(hipFuncSetAttribute((const void*)uph_map_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
+    UphEventTmp e0, e1;
+    HIPCHK(hipEventCreate((hipEvent_t*)&e0.e));
+    HIPCHK(hipEventCreate((hipEvent_t*)&e1.e));
     const int ncol = (x1 - x0) * g.ny;
-    HIPCHK(hipEventRecord(e0, 0));
+    HIPCHK(hipEventRecord((hipEvent_t)e0.e, 0));
     hipLaunchKernelGGL(uph_map_build_kernel, dim3(ncol), dim3(64), lds_bytes, 0, g, cd, m->d_cells, (int)x0, (int)x1, (int)m->mp.iter_num, m->mp.ellipsoid_x,
-                       m->mp.ellipsoid_y, m->mp.ellipsoid_z, cap);
+                       m->mp.ellipsoid_y, m->mp.ellipsoid_z, cap, t_ovf.as<int>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventRecord((hipEvent_t)e1.e, 0));
     HIPCHK(hipDeviceSynchronize());
+    int ovf = 0;
+    HIPCHK(hipMemcpy(&ovf, t_ovf.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (ovf) { setError("uph_map_build: a staged neighbourhood exceeded the LDS window (internal sizing error)"); return UPH_ERR_LIMIT; }
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)e0.e, (hipEvent_t)e1.e));
     m->last_build_ms = ms;
     m->last_cell_iters = (int64_t)ncol * g.nyaw * m->mp.iter_num;
     m->last_cloud = (int64_t)np;
-    hipFree(d_pts); hipFree(d_bstart);
     return commitMap(m);
+}
+
+/* the cloud the map is built from: UnevenMap::init's CropBox [-10,10]^2 x [-0.01,5] + VoxelGrid 1 cm (uneven_map.cpp:133-143) applied to
+ * xyz (n points); out_xyz receives at most cap points (may be NULL to query the count); returns the number of filtered points or < 0 */
+int64_t uph_map_filter_cloud(const float* xyz, int64_t n, float* out_xyz, int64_t cap) {
+    if (!xyz || n <= 0) { setError("uph_map_filter_cloud: bad arguments"); return UPH_ERR_INVALID; }
+    const HostCloud cl = cropAndVoxel(xyz, n);
+    const int64_t np = (int64_t)cl.size();
+    if (out_xyz) for (int64_t i = 0; i < np && i < cap; i++) { out_xyz[3 * i] = cl.x[i]; out_xyz[3 * i + 1] = cl.y[i]; out_xyz[3 * i + 2] = cl.z[i]; }
+    return np;
 }
 
 
@@ -526,28 +569,39 @@ int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x
 int uph_frontend_query(uph_map* m, const double* pos, int32_t n, double* sigma, int32_t* occ, int32_t* occ_xy) {
     if (!m || !pos || n <= 0 || (!sigma && !occ && !occ_xy)) { setError("uph_frontend_query: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
-    double *dp = nullptr, *ds = nullptr;
-    int32_t *d1 = nullptr, *d2 = nullptr;
-    HIPCHK(hipMalloc((void**)&dp, 8 * 3 * (size_t)n));
-    HIPCHK(hipMalloc((void**)&ds, 8 * (size_t)n));
-    HIPCHK(hipMalloc((void**)&d1, 4 * (size_t)n));
-    HIPCHK(hipMalloc((void**)&d2, 4 * (size_t)n));
-    HIPCHK(hipMemcpy(dp, pos, 8 * 3 * (size_t)n, hipMemcpyHostToDevice));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(uph_frontend_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, m->g, m->d_occ, m->d_occ2, dp, n, ds, d1, d2);
-    HIPCHK(hipEventRecord(e1, 0));
+    UphDevTmp tp, ts, t1, t2;
+    HIPCHK(hipMalloc(&tp.p, 8 * 3 * (size_t)n));
+    HIPCHK(hipMalloc(&ts.p, 8 * (size_t)n));
+    HIPCHK(hipMalloc(&t1.p, 4 * (size_t)n));
+    HIPCHK(hipMalloc(&t2.p, 4 * (size_t)n));
+    HIPCHK(hipMemcpy(tp.p, pos, 8 * 3 * (size_t)n, hipMemcpyHostToDevice));
+    UphEventTmp e0, e1;
+    HIPCHK(hipEventCreate((hipEvent_t*)&e0.e)); HIPCHK(hipEventCreate((hipEvent_t*)&e1.e));
+    HIPCHK(hipEventRecord((hipEvent_t)e0.e, 0));
+    hipLaunchKernelGGL(uph_frontend_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, m->g, m->d_occ, m->d_occ2, tp.as<double>(), n, ts.as<double>(), t1.as<int>(), t2.as<int>());
+    HIPCHK(hipEventRecord((hipEvent_t)e1.e, 0));
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)e0.e, (hipEvent_t)e1.e));
     m->last_query_ms = ms;
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    if (sigma) HIPCHK(hipMemcpy(sigma, ds, 8 * (size_t)n, hipMemcpyDeviceToHost));
-    if (occ) HIPCHK(hipMemcpy(occ, d1, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    if (occ_xy) HIPCHK(hipMemcpy(occ_xy, d2, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    hipFree(dp); hipFree(ds); hipFree(d1); hipFree(d2);
+    if (sigma) HIPCHK(hipMemcpy(sigma, ts.p, 8 * (size_t)n, hipMemcpyDeviceToHost));
+    if (occ) HIPCHK(hipMemcpy(occ, t1.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    if (occ_xy) HIPCHK(hipMemcpy(occ_xy, t2.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return UPH_OK;
+}
+/* batched UnevenMap::getTerrainPos (uneven_map.h:203-218) on the device grid: pose12[n][12] = rotation (column-major: x_b, y_b, z_b), position */
+int uph_terrain_pose_query(uph_map* m, const double* pos, int32_t n, double* pose12) {
+    if (!m || !pos || n <= 0 || !pose12) { setError("uph_terrain_pose_query: bad arguments"); return UPH_ERR_INVALID; }
+    HIPCHK(hipSetDevice(m->device));
+    UphDevTmp tp, to;
+    HIPCHK(hipMalloc(&tp.p, 8 * 3 * (size_t)n));
+    HIPCHK(hipMalloc(&to.p, 8 * 12 * (size_t)n));
+    HIPCHK(hipMemcpy(tp.p, pos, 8 * 3 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(uph_pose_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, m->g, tp.as<double>(), n, to.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(pose12, to.p, 8 * 12 * (size_t)n, hipMemcpyDeviceToHost));
     return UPH_OK;
 }
 int uph_frontend_query_ms(uph_map* m, double* kernel_ms) { if (!m || !kernel_ms) return UPH_ERR_INVALID; *kernel_ms = m->last_query_ms; return UPH_OK; }

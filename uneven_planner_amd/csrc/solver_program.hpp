@@ -1301,9 +1301,14 @@ struct Solver {
             cnt = (int)cnt_d[0];
         }
         const double gravity = grid.gravity;
+        // sample q sits at the reference's running sum t += 0.01 (q additions): every lane walks its own samples in increasing order
+        // and keeps adding where it stopped
+        double tcur = 0.0;
+        int qcur = 0;
         auto sampleAt = [&](int q, double out[7]) {
-            double t = 0.0;
-            for (int w = 0; w < q; w++) t += 0.01;
+            if (q < qcur) { tcur = 0.0; qcur = 0; }
+            for (; qcur < q; qcur++) tcur += 0.01;
+            const double t = tcur;
             // locatePieceIdx (se2traj.hpp:343-361) with uniform durations
             double tl = t; int ix = 0;
             for (; ix < Nxy && tl > Tx; ix++) tl -= Tx;
@@ -1345,19 +1350,28 @@ struct Solver {
             out[5] = tv[6];
             out[6] = fabs(v[0] * sy_ + v[1] * (-cy_));
         };
-        double o[7];
-        for (int f = 0; f < 4; f++) {        // signed value of largest magnitude (alm_traj_opt.h:201-216)
-            const int ff = f;
-            const double pos = wg.maxv(cnt, [&](int q) { double r[7]; sampleAt(q, r); return r[ff]; });
-            const double neg = wg.maxv(cnt, [&](int q) { double r[7]; sampleAt(q, r); return -r[ff]; });
-            o[f] = pos >= neg ? pos : -neg;
-        }
-        // att = -1/invCosXi = -cos xi (negative): max over samples, started at -1 (alm_traj_opt.h:177); sigma started at 0
-        const double natt = wg.maxv(cnt, [&](int q) { double r[7]; sampleAt(q, r); return r[4] + 1.0; });   // shift so that the floor 0 == -1
-        o[4] = natt - 1.0;
-        o[5] = wg.maxv(cnt, [&](int q) { double r[7]; sampleAt(q, r); return r[5]; });
-        double e1[1];
-        wg.template sum<1>(cnt, e1, [&](int q, double* acc) { double r[7]; sampleAt(q, r); acc[0] += r[6]; });
+        // two passes: max of +v and of -v for vx, ax, ay, cur (signed value of largest magnitude, alm_traj_opt.h:201-216), att
+        // (= -cos xi, started at -1, :177: shifted by one so that the floor is 0), sigma, and the non-holonomic error sum
+        double o[7], e1[1], ma[7], mb[3], dum[1];
+        wg.template sumMax<1, 7>(cnt, e1, ma, [&](int q, double* acc, double* mx) {
+            double r[7];
+            sampleAt(q, r);
+            acc[0] += r[6];
+            mx[0] = dmax(mx[0], r[0]); mx[1] = dmax(mx[1], -r[0]); mx[2] = dmax(mx[2], r[1]); mx[3] = dmax(mx[3], -r[1]);
+            mx[4] = dmax(mx[4], r[2]); mx[5] = dmax(mx[5], -r[2]); mx[6] = dmax(mx[6], r[3]);
+        });
+        wg.template sumMax<1, 3>(cnt, dum, mb, [&](int q, double* acc, double* mx) {
+            double r[7];
+            sampleAt(q, r);
+            acc[0] += 0.0;
+            mx[0] = dmax(mx[0], -r[3]); mx[1] = dmax(mx[1], r[4] + 1.0); mx[2] = dmax(mx[2], r[5]);
+        });
+        o[0] = ma[0] >= ma[1] ? ma[0] : -ma[1];
+        o[1] = ma[2] >= ma[3] ? ma[2] : -ma[3];
+        o[2] = ma[4] >= ma[5] ? ma[4] : -ma[5];
+        o[3] = ma[6] >= mb[0] ? ma[6] : -mb[0];
+        o[4] = mb[1] - 1.0;
+        o[5] = mb[2];
         o[6] = e1[0];
         wg.pfor(7, [&](int t) { bd.report[(size_t)bidx * 7 + t] = o[t]; });
     }

@@ -1,5 +1,5 @@
 // libunevenhip.so -- optimiser half: gfx950 kernels + the C-ABI declared in include/uneven_hip.h.
-// One persistent 256-lane workgroup per trajectory runs the whole ALM / L-BFGS / MINCO solve (solver_program.hpp).
+// One persistent workgroup (64, 128 or 256 lanes) per trajectory runs the whole ALM / L-BFGS / MINCO solve (solver_program.hpp).
 // The map half (plane-fit build) lives in map_build.hip.
 #include <hip/hip_runtime.h>
 
@@ -480,7 +480,8 @@ struct uph_ctx {
     int wps_forced = 0;                     // experiment knob: register-capped (2) or uncapped (1) build regardless of batch size
     DevBuf d_thomas, d_rsd, d_rs;
     DevBuf d_desc, d_state, d_x, d_x0, d_gout, d_dual, d_res, d_scl, d_cxy, d_cyaw, d_hist, d_report, d_order, d_trace;
-    int trace_cap = 0;
+    int trace_cap = 0;                      // requested for the next upload
+    int trace_cap_up = 0;                   // what the uploaded batch's trace buffer was sized for
     std::vector<TrajState> state_host;
     // stats of the last solve
     double last_ms = 0.0, last_prepare_ms = 0.0;
@@ -508,8 +509,8 @@ static BatchDev makeBatchDev(uph_ctx* c) {
     bd.cxy = c->d_cxy.as<double>(); bd.cyaw = c->d_cyaw.as<double>();
     bd.hist = c->d_hist.as<double>();
     bd.report = c->d_report.as<double>();
-    bd.trace = c->trace_cap > 0 ? c->d_trace.as<double>() : nullptr;
-    bd.trace_cap = c->trace_cap;
+    bd.trace = c->trace_cap_up > 0 ? c->d_trace.as<double>() : nullptr;
+    bd.trace_cap = c->trace_cap_up;
     bd.order = c->d_order.as<int>();
     bd.thomas = c->d_thomas.as<double>();
     bd.rs_d = c->d_rsd.as<double>(); bd.rs = c->d_rs.as<double>();
@@ -665,9 +666,9 @@ int uph_ctx_get_rho(uph_ctx* c, double* rho) { if (!c || !rho) return UPH_ERR_IN
 // diagnostic: keep the first `cap` entries of every trajectory's cost trace (0 = off); read back with uph_ctx_get_trace
 int uph_ctx_set_trace(uph_ctx* c, int32_t cap) { if (!c || cap < 0) return UPH_ERR_INVALID; c->trace_cap = cap; return UPH_OK; }
 int uph_ctx_get_trace(uph_ctx* c, double* out /* B x cap */) {
-    if (!c || !out || c->trace_cap <= 0 || c->B <= 0) return UPH_ERR_INVALID;
+    if (!c || !out || c->trace_cap_up <= 0 || c->B <= 0) return UPH_ERR_INVALID;
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
-    HIPCHK(hipMemcpy(out, c->d_trace.p, sizeof(double) * (size_t)c->B * c->trace_cap, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, c->d_trace.p, sizeof(double) * (size_t)c->B * c->trace_cap_up, hipMemcpyDeviceToHost));
     return UPH_OK;
 }
 
@@ -675,6 +676,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     if (!c || B <= 0 || !probs) { setError("uph_batch_upload: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     const int K1 = c->P.int_K + 1, mem = c->P.mem_size;
+    c->B = 0;                       // the context holds no batch until this upload has succeeded as a whole
     c->desc.assign(B, TrajDesc());
     int64_t on = 0, os = 0, ocx = 0, ocy = 0, oh = 0;
     size_t lds_d = 0;
@@ -703,10 +705,8 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         c->fp_bytes[b] = (Solver<DevWG<64>>::ldsDoubles(Nxy, Nyaw, t.n, c->lanes, mem, c->P.int_K) + 2 * (c->lanes / 64) * DevWG<64>::MAXM) * sizeof(double);
         lds_d = std::max(lds_d, Solver<DevWG<64>>::ldsDoubles(Nxy, Nyaw, t.n, c->lanes, mem, c->P.int_K));
     }
-    c->B = B; c->sum_n = on; c->sum_S = os; c->sum_cxy = ocx; c->sum_cyaw = ocy; c->sum_hist = oh;
+    c->sum_n = on; c->sum_S = os; c->sum_cxy = ocx; c->sum_cyaw = ocy; c->sum_hist = oh;
     c->lds_bytes = (lds_d + 2 * (c->lanes / 64) * DevWG<64>::MAXM) * sizeof(double);     // program arrays + DevWG<lanes>::SCRATCH
-    if (const char* pad = getenv("UPH_LDS_PAD")) c->lds_bytes += (size_t)atoi(pad);      // experiment knob: occupancy vs LDS footprint
-    if (getenv("UPH_VERBOSE")) fprintf(stderr, "[uph] upload B=%d lanes=%d wps=%d lds_bytes=%zu\n", B, c->lanes, c->wps, c->lds_bytes);
     if (c->lds_bytes > 160 * 1024) { setError("uph_batch_upload: trajectory does not fit the 160 KiB LDS"); return UPH_ERR_LIMIT; }
     if (c->ops_dirty) {
         if (c->d_ops.ensure(sizeof(MincoOp) * c->ops_host.size())) return UPH_ERR_HIP;
@@ -753,10 +753,9 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         size_t mmain = 0, mbig = 0;
         int nbig = 0;
         for (int b = 0; b < B; b++) { if (c->fp_bytes[b] > limit) { nbig++; mbig = std::max(mbig, c->fp_bytes[b]); } else mmain = std::max(mmain, c->fp_bytes[b]); }
-        if (nbig > 0 && nbig < B && !getenv("UPH_LDS_PAD")) {
+        if (nbig > 0 && nbig < B) {
             std::stable_partition(c->order.begin(), c->order.end(), [&](int a) { return c->fp_bytes[a] <= limit; });
             c->n_main = B - nbig; c->lds_bytes = mmain; c->lds_big = mbig;
-            if (getenv("UPH_VERBOSE")) fprintf(stderr, "[uph] residency classes: %d trajectories at %zu B, %d oversize at %zu B\n", c->n_main, mmain, nbig, mbig);
         }
     }
     c->state_host.assign(B, TrajState());
@@ -773,6 +772,8 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     std::vector<double> ones(7 * os, 1.0);
     HIPCHK(hipMemcpy(c->d_scl.p, ones.data(), 8 * 7 * os, hipMemcpyHostToDevice));
     if (c->trace_cap > 0) HIPCHK(hipMemset(c->d_trace.p, 0, 8 * (size_t)c->trace_cap * B));
+    c->trace_cap_up = c->trace_cap;
+    c->B = B;
     return UPH_OK;
 }
 
@@ -1041,17 +1042,16 @@ int uph_batch_get_lbfgs_state(uph_ctx* c, double* g, double* d, double* pf, doub
 int uph_terrain_query(uph_map* m, const double* pos, int32_t n, double* values7, double* grads21) {
     if (!m || !pos || n <= 0 || !values7 || !grads21) { setError("uph_terrain_query: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(uphMapDevice(m)));
-    double *dp = nullptr, *dv = nullptr, *dg = nullptr;
-    HIPCHK(hipMalloc((void**)&dp, 8 * 3 * (size_t)n));
-    HIPCHK(hipMalloc((void**)&dv, 8 * 7 * (size_t)n));
-    HIPCHK(hipMalloc((void**)&dg, 8 * 21 * (size_t)n));
-    HIPCHK(hipMemcpy(dp, pos, 8 * 3 * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(uph_terrain_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, uphMapGrid(m), dp, n, dv, dg);
+    UphDevTmp tp, tv, tg;
+    HIPCHK(hipMalloc(&tp.p, 8 * 3 * (size_t)n));
+    HIPCHK(hipMalloc(&tv.p, 8 * 7 * (size_t)n));
+    HIPCHK(hipMalloc(&tg.p, 8 * 21 * (size_t)n));
+    HIPCHK(hipMemcpy(tp.p, pos, 8 * 3 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(uph_terrain_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, uphMapGrid(m), tp.as<double>(), n, tv.as<double>(), tg.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(values7, dv, 8 * 7 * (size_t)n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(grads21, dg, 8 * 21 * (size_t)n, hipMemcpyDeviceToHost));
-    hipFree(dp); hipFree(dv); hipFree(dg);
+    HIPCHK(hipMemcpy(values7, tv.p, 8 * 7 * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(grads21, tg.p, 8 * 21 * (size_t)n, hipMemcpyDeviceToHost));
     return UPH_OK;
 }
 

@@ -11,3 +11,14 @@ void setError(const std::string& s);
 
 int uphMapDevice(const uph_map* m);
 uph::GridDev uphMapGrid(const uph_map* m);
+
+// scope guards for the temporaries of the extern "C" entry points: every early return (HIPCHK) releases them
+struct UphDevTmp {
+    void* p = nullptr;
+    ~UphDevTmp();
+    template <class T> T* as() { return (T*)p; }
+};
+struct UphEventTmp {
+    void* e = nullptr;          // hipEvent_t
+    ~UphEventTmp();
+};

@@ -112,8 +112,32 @@ class HostGridView:
                  math.ceil((2.0 * math.pi + 5e-2) / yaw_resolution))
         view = cls(np.zeros((ncell, 4)), map_size_x, map_size_y, xy_resolution, yaw_resolution)
         nx, ny, nyaw = (int(v) for v in view.voxel_num)
-        arr = np.loadtxt(path, delimiter=",", dtype=np.float64).reshape(-1, 7)
+        # the reference parses the four values with stold and narrows to double (uneven_map.cpp:296-299): two roundings, which a direct
+        # string -> double conversion does not always reproduce (1 ulp on ~1e-4 of the values)
+        arr = np.loadtxt(path, delimiter=",", dtype=np.longdouble).reshape(-1, 7)
         ix, iy, iw = arr[:, 0].astype(int), arr[:, 1].astype(int), arr[:, 2].astype(int)
         ok = (ix >= 0) & (iy >= 0) & (iw >= 0) & (ix < nx) & (iy < ny) & (iw < nyaw)
-        view.cells[ix[ok], iy[ok], iw[ok]] = arr[ok, 3:7]
+        view.cells[ix[ok], iy[ok], iw[ok]] = arr[ok, 3:7].astype(np.float64)
+        return view
+
+    # ---- binary side-car of the `.map` cache: header (magic, nx, ny, nyaw) + ncell x 4 float64, bit-exact
+    MAGIC = b"UPHMAP01"
+
+    def write_map_binary(self, path):
+        with open(path, "wb") as f:
+            f.write(self.MAGIC)
+            f.write(np.asarray(self.voxel_num, dtype="<i8").tobytes())
+            f.write(np.ascontiguousarray(self.cells, dtype="<f8").tobytes())
+
+    @classmethod
+    def read_map_binary(cls, path, map_size_x=10.0, map_size_y=10.0, xy_resolution=0.05, yaw_resolution=0.1):
+        with open(path, "rb") as f:
+            if f.read(8) != cls.MAGIC:
+                raise ValueError("%s is not a binary .map side-car" % path)
+            dims = np.frombuffer(f.read(24), dtype="<i8")
+            cells = np.frombuffer(f.read(), dtype="<f8")
+        view = cls(np.zeros((int(np.prod(dims)), 4)), map_size_x, map_size_y, xy_resolution, yaw_resolution)
+        if not np.array_equal(dims, view.voxel_num) or cells.size != view.cells.size:
+            raise ValueError("%s was written for a %s grid, this map is %s" % (path, dims.tolist(), view.voxel_num.tolist()))
+        view.cells[...] = cells.reshape(view.cells.shape)
         return view

@@ -24,6 +24,27 @@ def _dp(a):
     return a.ctypes.data_as(_lib.DP)
 
 
+# ---- x-slab sharding of constructMap over the ranks of one node ----------------------------------------------------
+# The cell array is x-slowest (uneven_map.h:427-435), so the x-slab of a rank is one contiguous block and the exchange is ONE
+# all-gather of equally sized blocks (the last block is zero-padded when nx does not divide).  These two helpers are the whole
+# rule; UnevenMap.build_sharded runs them around the device kernel with RCCL, the CPU tier runs them around the oracle with gloo.
+def slab_bounds(nx, rank, world):
+    """(rows per rank, x0, x1): rank r fits x in [x0, x1)"""
+    per = -(-int(nx) // int(world))
+    x0 = min(rank * per, nx)
+    return per, x0, min(x0 + per, nx)
+
+
+def gather_slabs(slab, nx, row_elems, world, all_gather):
+    """slab: this rank's rows as a 1-D torch tensor of per * row_elems elements (zero-padded); all_gather(full, slab) fills a tensor
+    of world * per rows; returns the first nx rows = the complete cell array, identical on every rank"""
+    import torch
+    per = slab.numel() // row_elems
+    full = torch.empty(world * per * row_elems, dtype=slab.dtype, device=slab.device)
+    all_gather(full, slab)
+    return full[:nx * row_elems]
+
+
 class UnevenMap:
     def __init__(self, params=None, device=0):
         self.L = _lib.load()
@@ -60,7 +81,9 @@ class UnevenMap:
     def init(self, pcd_file=None, map_file=None, xyz=None):
         """UnevenMap::init (uneven_map.cpp:73-268), data part: read the cloud, then constructMapInput() (the `.map`
         text cache) if it exists, else constructMap() on the GPU and write the cache."""
-        if map_file and os.path.exists(map_file):
+        if map_file and os.path.exists(map_file + ".bin"):
+            self.constructMapInputBinary(map_file + ".bin")      # bit-exact side-car of the 6-digit CSV (written below)
+        elif map_file and os.path.exists(map_file):
             self.constructMapInput(map_file)
         else:
             if xyz is None:
@@ -68,6 +91,7 @@ class UnevenMap:
             self.build(xyz)
             if map_file:
                 self.write_map_file(map_file)
+                self.write_map_binary(map_file + ".bin")
         return self
 
     def build(self, xyz, x0=0, x1=None, download=True):
@@ -82,6 +106,19 @@ class UnevenMap:
             self.download()
         self.map_ready = True
         return self
+
+    @staticmethod
+    def filter_cloud(xyz):
+        """CropBox + 1 cm VoxelGrid of UnevenMap::init (uneven_map.cpp:133-143) as uph_map_build applies them; returns the (m,3) float32 cloud"""
+        L = _lib.load()
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        fp = C.POINTER(C.c_float)
+        n = L.uph_map_filter_cloud(xyz.ctypes.data_as(fp), xyz.shape[0], None, 0)
+        if n < 0:
+            _lib.check(int(n), "uph_map_filter_cloud")
+        out = np.zeros((int(n), 3), dtype=np.float32)
+        L.uph_map_filter_cloud(xyz.ctypes.data_as(fp), xyz.shape[0], out.ctypes.data_as(fp), int(n))
+        return out
 
     def build_stats(self):
         ms, ci, cp = C.c_double(0), C.c_int64(0), C.c_int64(0)
@@ -113,21 +150,20 @@ class UnevenMap:
         return p.value, nb.value
 
     def build_sharded(self, xyz, rank, world, all_gather):
-        """constructMap sharded over `world` ranks: rank r fits the x-slab [r*nx/world, (r+1)*nx/world), then ONE
-        all-gather of the slabs (RCCL over xGMI when `all_gather` is torch.distributed.all_gather_into_tensor on CUDA tensors;
-        gloo in the CPU tests).  `all_gather(full_tensor, slab_tensor)` works on torch float64 tensors."""
+        """constructMap sharded over `world` ranks: rank r fits its x-slab (slab_bounds), then ONE all-gather of the
+        slabs (RCCL over xGMI when `all_gather` is torch.distributed.all_gather_into_tensor on CUDA tensors) and every rank
+        imports the complete cell array.  `all_gather(full_tensor, slab_tensor)` works on torch float64 tensors."""
         import torch
         nx, ny, nyaw = (int(v) for v in self.voxel_num)
-        assert nx % world == 0, "x extent must divide by the world size"
-        per = nx // world
-        x0, x1 = rank * per, (rank + 1) * per
-        self.build(xyz, x0=x0, x1=x1, download=False)
+        row = ny * nyaw * 4
+        per, x0, x1 = slab_bounds(nx, rank, world)
         dev = torch.device("cuda", self.device)
-        slab = torch.empty(per * ny * nyaw * 4, dtype=torch.float64, device=dev)
-        full = torch.empty(nx * ny * nyaw * 4, dtype=torch.float64, device=dev)
-        _lib.check(self.L.uph_map_export_slab_dev(self.h, x0, x1, C.c_void_p(slab.data_ptr())), "uph_map_export_slab_dev")
+        slab = torch.zeros(per * row, dtype=torch.float64, device=dev)
+        if x1 > x0:
+            self.build(xyz, x0=x0, x1=x1, download=False)
+            _lib.check(self.L.uph_map_export_slab_dev(self.h, x0, x1, C.c_void_p(slab.data_ptr())), "uph_map_export_slab_dev")
         torch.cuda.synchronize(dev)
-        all_gather(full, slab)
+        full = gather_slabs(slab, nx, row, world, all_gather).contiguous()
         torch.cuda.synchronize(dev)
         _lib.check(self.L.uph_map_import_cells_dev(self.h, C.c_void_p(full.data_ptr())), "uph_map_import_cells_dev")
         self.download()
@@ -142,6 +178,16 @@ class UnevenMap:
     def write_map_file(self, path):
         """CSV `x,y,yaw,z,sigma,zbx,zby`, default ostream precision (6 significant digits) like the reference."""
         self.host.write_map_file(path)
+
+    def write_map_binary(self, path):
+        """binary side-car of the `.map` cache: the CSV keeps 6 significant digits (uneven_map.cpp:400-412), so a grid read back
+        from it differs from the built one by ~1e-6; this file holds the float64 cells bit for bit"""
+        self.host.write_map_binary(path)
+
+    def constructMapInputBinary(self, path):
+        view = HostGridView.read_map_binary(path, self.params["map_size_x"], self.params["map_size_y"], self.xy_resolution, self.yaw_resolution)
+        self.set_cells(view.cells.reshape(-1, 4))
+        return True
 
     def constructMapInput(self, path):
         view = HostGridView.read_map_file(path, self.params["map_size_x"], self.params["map_size_y"], self.xy_resolution, self.yaw_resolution)
@@ -208,6 +254,13 @@ class UnevenMap:
         ip = lambda a: a.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int32))
         _lib.check(self.L.uph_frontend_query(self.h, _dp(pos), n, _dp(sg), ip(oc), ip(oxy)), "uph_frontend_query")
         return sg, oc, oxy
+
+    def getTerrainPosBatch(self, pos):
+        """batched getTerrainPos (uneven_map.h:203-218) on the device grid: pos (n,3) -> R (n,3,3) with columns x_b, y_b, z_b and p (n,3)"""
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros((pos.shape[0], 12))
+        _lib.check(self.L.uph_terrain_pose_query(self.h, _dp(pos), pos.shape[0], _dp(out)), "uph_terrain_pose_query")
+        return out[:, :9].reshape(-1, 3, 3).transpose(0, 2, 1).copy(), out[:, 9:].copy()
 
     def frontend_query_ms(self):
         ms = _lib.C.c_double(0.0)
