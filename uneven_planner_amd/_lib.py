@@ -105,6 +105,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise UnevenHipError("libunevenhip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                                  "there is no CPU fall-back")
+        # PyTorch-ROCm wheels bundle their own copy of the HIP runtime (same soname, different file).  A process must run on ONE
+        # runtime: if libunevenhip.so pulls in /opt/rocm's first, torch later loads its bundled one next to it and finds "no HIP
+        # GPUs".  Loading torch first makes both resolve to the same library.  (Only where torch is installed; the C++ adapter has no
+        # such concern.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)       # AttributeError if the symbol is not exported
