@@ -1,5 +1,6 @@
 // uneven_hip_adapter.hpp -- header-only C++ adapter that gives libunevenhip.so the member names PlanManager uses on the
-// reference's ALMTrajOpt, so that plan_manager.cpp compiles unchanged against it (INTEGRATION.md shows the two-line swap).
+// reference's ALMTrajOpt and SE2Trajectory (plan_manager/src/plan_manager.cpp:17-22, 134-185), so that the goal callback compiles
+// against it as it stands (INTEGRATION.md shows the swap).
 //
 // Mirrors (paths under /root/reference/src/uneven_planner):
 //   ALMTrajOpt::optimizeSE2Traj   back_end/include/back_end/alm_traj_opt.h:92-98   (same argument list, same 0/1/2 return)
@@ -7,13 +8,18 @@
 //                                                            (MinJerkOpt::getTraj, back_end/include/utils/se2traj.hpp:682-695)
 //   ALMTrajOpt::setEnvironment    alm_traj_opt.h:127-130
 //   public parameter members      alm_traj_opt.h:29-53
+//   getMaxVxAxAyCurAttSig         alm_traj_opt.h:170-229 (device report), init / setFrontend / visSE2Traj / visSE3Traj (no-ops here)
+//   Piece / PolyTrajectory / SE2Trajectory   back_end/include/utils/se2traj.hpp:30-150, 253-406, 408-562 (evaluation members, getNonHolError)
+//   mpc_controller/SE2Traj filler  plan_manager.cpp:150-182, mpc_controller/msg/SE2Traj.msg:1-9
 //
 // The matrix/vector types are template parameters: anything with data(), rows(), cols()/size() and column-major storage works
 // (Eigen::MatrixXd / Eigen::VectorXd in the ROS workspace; the tiny Mat/Vec below where Eigen is not installed, as in this
 // repository's image).  No Eigen header is included here.
 #pragma once
+#include <cmath>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "uneven_hip.h"
@@ -34,20 +40,151 @@ struct Mat {                       // minimal column-major stand-in with the Eig
     double operator()(int i, int j) const { return v[(size_t)j * r + i]; }
 };
 
-struct Piece {                     // se2traj.hpp:30-43: duration + D x 6 coefficients, highest order first
-    double duration;
-    int dim;
-    double coeff[2][6];
+// column vector of D doubles: Eigen's own type where Eigen is installed (so that `Eigen::Vector2d p = traj.pos_traj[i].getValue(0.0)`
+// compiles unchanged), a minimal stand-in otherwise
+#if __has_include(<Eigen/Core>)
+}  // namespace uneven_hip
+#include <Eigen/Core>
+namespace uneven_hip {
+template <int D> using VecN = Eigen::Matrix<double, D, 1>;
+template <int D> inline VecN<D> vecZero() { return VecN<D>::Zero(); }
+#else
+template <int D>
+struct VecN {
+    double v[D];
+    double operator[](int i) const { return v[i]; }
+    double& operator[](int i) { return v[i]; }
+    double operator()(int i) const { return v[i]; }
+    double& operator()(int i) { return v[i]; }
+    double x() const { return v[0]; }
+    double y() const { return v[D > 1 ? 1 : 0]; }
 };
-struct SE2Trajectory {             // se2traj.hpp:408-413
-    std::vector<Piece> pos_traj, yaw_traj;
-    double getTotalDuration() const {
-        double a = 0, b = 0;
-        for (const Piece& p : pos_traj) a += p.duration;
-        for (const Piece& p : yaw_traj) b += p.duration;
-        return a < b ? a : b;
+template <int D> inline VecN<D> vecZero() { VecN<D> z; for (int d = 0; d < D; d++) z.v[d] = 0.0; return z; }
+#endif
+
+// Piece<Dim> (se2traj.hpp:30-150): duration + Dim x 6 coefficients, highest order first; the three evaluators follow the reference's loops
+template <int Dim>
+class Piece {
+public:
+    double duration = 0.0;
+    double coeff[Dim][6];
+    int getDim() const { return Dim; }
+    int getOrder() const { return 5; }
+    double getDuration() const { return duration; }
+    VecN<Dim> getValue(const double& t) const {                         // :106-116
+        VecN<Dim> value = vecZero<Dim>();
+        double tn = 1.0;
+        for (int i = 5; i >= 0; i--) { for (int d = 0; d < Dim; d++) value[d] += tn * coeff[d][i]; tn *= t; }
+        return value;
+    }
+    VecN<Dim> getDotValue(const double& t) const {                      // :118-131
+        VecN<Dim> value = vecZero<Dim>();
+        double tn = 1.0;
+        int n = 1;
+        for (int i = 4; i >= 0; i--) { for (int d = 0; d < Dim; d++) value[d] += n * tn * coeff[d][i]; tn *= t; n++; }
+        return value;
+    }
+    VecN<Dim> getDDotValue(const double& t) const {                     // :133-150
+        VecN<Dim> value = vecZero<Dim>();
+        double tn = 1.0;
+        int m = 1, n = 2;
+        for (int i = 3; i >= 0; i--) { for (int d = 0; d < Dim; d++) value[d] += m * n * tn * coeff[d][i]; tn *= t; m++; n++; }
+        return value;
     }
 };
+
+// PolyTrajectory<Dim> (se2traj.hpp:253-406): the members PlanManager, the report and the MPC message filler use
+template <int Dim>
+class PolyTrajectory {
+public:
+    std::vector<Piece<Dim>> pieces;
+    int getPieceNum() const { return (int)pieces.size(); }
+    double getTotalDuration() const {                                   // :290-299
+        double total = 0.0;
+        for (const Piece<Dim>& p : pieces) total += p.getDuration();
+        return total;
+    }
+    const Piece<Dim>& operator[](int i) const { return pieces[i]; }
+    Piece<Dim>& operator[](int i) { return pieces[i]; }
+    typename std::vector<Piece<Dim>>::const_iterator begin() const { return pieces.begin(); }
+    typename std::vector<Piece<Dim>>::const_iterator end() const { return pieces.end(); }
+    void clear() { pieces.clear(); }
+    void emplace_back(const Piece<Dim>& p) { pieces.emplace_back(p); }
+    int locatePieceIdx(double& t) const {                               // :343-361
+        const int N = getPieceNum();
+        int idx;
+        double dur;
+        for (idx = 0; idx < N && t > (dur = pieces[idx].getDuration()); idx++) t -= dur;
+        if (idx == N) { idx--; t += pieces[idx].getDuration(); }
+        return idx;
+    }
+    VecN<Dim> getValue(double t) const { const int i = locatePieceIdx(t); return pieces[i].getValue(t); }
+    VecN<Dim> getDotValue(double t) const { const int i = locatePieceIdx(t); return pieces[i].getDotValue(t); }
+    VecN<Dim> getDDotValue(double t) const { const int i = locatePieceIdx(t); return pieces[i].getDDotValue(t); }
+};
+
+class SE2Trajectory {              // se2traj.hpp:408-562
+public:
+    PolyTrajectory<2> pos_traj;
+    PolyTrajectory<1> yaw_traj;
+    double getTotalDuration() const { const double a = pos_traj.getTotalDuration(), b = yaw_traj.getTotalDuration(); return a < b ? a : b; }
+    VecN<2> getPos(double t) const { return pos_traj.getValue(t); }
+    VecN<2> getVel(double t) const { return pos_traj.getDotValue(t); }
+    VecN<2> getAcc(double t) const { return pos_traj.getDDotValue(t); }
+    double getAngle(double t) const { return yaw_traj.getValue(t)[0]; }
+    double getAngleRate(double t) const { return yaw_traj.getDotValue(t)[0]; }
+    double getNonHolError() const {                                     // :551-561
+        double error = 0.0;
+        for (double t = 0.0; t < getTotalDuration(); t += 0.01) {
+            const VecN<2> v = getVel(t);
+            const double yaw = getAngle(t);
+            error += std::fabs(v[0] * std::sin(yaw) + v[1] * (-std::cos(yaw)));
+        }
+        return error;
+    }
+};
+
+// mpc_controller/SE2Traj (mpc_controller/msg/SE2Traj.msg:1-9) as plain data, and the filler PlanManager runs before publishing
+// (plan_manager.cpp:150-182): piece start points + the end point, piece durations, zero init_v / init_a.  fillSE2TrajMsg is a
+// template, so the real ROS message type works as well as this stand-in (start_time is left to the caller: ros::Time::now()).
+struct Point3 { double x = 0.0, y = 0.0, z = 0.0; };
+struct SE2TrajMsg {
+    double start_time = 0.0;
+    std::vector<Point3> pos_pts, angle_pts;
+    Point3 init_v, init_a;
+    std::vector<double> posT_pts, angleT_pts;
+};
+template <class Msg>
+inline void fillSE2TrajMsg(const SE2Trajectory& traj, Msg& msg) {
+    typedef typename std::remove_reference<decltype(msg.pos_pts[0])>::type Pt;
+    msg.init_v.x = 0.0; msg.init_v.y = 0.0; msg.init_v.z = 0.0;
+    msg.init_a.x = 0.0; msg.init_a.y = 0.0; msg.init_a.z = 0.0;
+    msg.pos_pts.clear(); msg.posT_pts.clear(); msg.angle_pts.clear(); msg.angleT_pts.clear();
+    for (int i = 0; i < traj.pos_traj.getPieceNum(); i++) {
+        Pt pt{};
+        const VecN<2> pos = traj.pos_traj[i].getValue(0.0);
+        pt.x = pos[0]; pt.y = pos[1];
+        msg.pos_pts.push_back(pt);
+        msg.posT_pts.push_back(traj.pos_traj[i].getDuration());
+    }
+    {
+        Pt pt{};
+        const VecN<2> pos = traj.pos_traj.getValue(traj.pos_traj.getTotalDuration());
+        pt.x = pos[0]; pt.y = pos[1];
+        msg.pos_pts.push_back(pt);
+    }
+    for (int i = 0; i < traj.yaw_traj.getPieceNum(); i++) {
+        Pt pt{};
+        pt.x = traj.yaw_traj[i].getValue(0.0)[0];
+        msg.angle_pts.push_back(pt);
+        msg.angleT_pts.push_back(traj.yaw_traj[i].getDuration());
+    }
+    {
+        Pt pt{};
+        pt.x = traj.yaw_traj.getValue(traj.yaw_traj.getTotalDuration())[0];
+        msg.angle_pts.push_back(pt);
+    }
+}
 
 class UnevenMapHandle {            // owns a uph_map; what UnevenMap::Ptr is to the reference's optimiser
 public:
@@ -62,6 +199,10 @@ public:
         int32_t d[3];
         uph_map_dims(m_, d);
         if (uph_map_build(m_, xyz, n, 0, d[0]) != UPH_OK) throw std::runtime_error(std::string("uph_map_build: ") + uph_last_error());
+    }
+    // UnevenMap::constructMapInput replacement: cells from the `.map` cache (ncell x 4: z, sigma, zb.x, zb.y in the reference's address order)
+    void setCells(const double* rxs2) {
+        if (uph_map_set_cells(m_, rxs2) != UPH_OK) throw std::runtime_error(std::string("uph_map_set_cells: ") + uph_last_error());
     }
     // fills the host members of the reference's UnevenMap (map_buffer as 4 doubles per cell, c_buffer, occ_buffer, occ_r2_buffer)
     void download(double* rxs2, double* c, char* occ, char* occ_r2) { uph_map_get_cells(m_, rxs2, c, occ, occ_r2); }
@@ -126,18 +267,31 @@ public:
         SE2Trajectory t;
         const int Nxy = (int)cxy_.size() / 12, Nyaw = (int)cyaw_.size() / 6;
         for (int i = 0; i < Nxy; i++) {
-            Piece p; p.duration = last_.piece_T_xy; p.dim = 2;
+            Piece<2> p; p.duration = last_.piece_T_xy;
             for (int d = 0; d < 2; d++) for (int k = 0; k < 6; k++) p.coeff[d][5 - k] = cxy_[(size_t)(6 * i + k) * 2 + d];
-            t.pos_traj.push_back(p);
+            t.pos_traj.emplace_back(p);
         }
         for (int i = 0; i < Nyaw; i++) {
-            Piece p; p.duration = last_.piece_T_yaw; p.dim = 1;
-            for (int k = 0; k < 6; k++) { p.coeff[0][5 - k] = cyaw_[(size_t)6 * i + k]; p.coeff[1][5 - k] = 0.0; }
-            t.yaw_traj.push_back(p);
+            Piece<1> p; p.duration = last_.piece_T_yaw;
+            for (int k = 0; k < 6; k++) p.coeff[0][5 - k] = cyaw_[(size_t)6 * i + k];
+            t.yaw_traj.emplace_back(p);
         }
         return t;
     }
     double getTrajJerkCost() const { return last_.jerk_cost; }   // minco_se2.getTrajJerkCost() (alm_traj_opt.cpp:273)
+
+    // getMaxVxAxAyCurAttSig (alm_traj_opt.h:170-229): max vx, ax, ay, curvature, attitude (-cos xi), sigma sampled every 0.01 s -- evaluated
+    // on the device for the trajectory of the last optimizeSE2Traj (the argument is what getTraj() returned for it)
+    std::vector<double> getMaxVxAxAyCurAttSig(const SE2Trajectory&) {
+        double o[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (uph_report_batch(ctx_, o) != UPH_OK) throw std::runtime_error(std::string("uph_report_batch: ") + uph_last_error());
+        return std::vector<double>(o, o + 6);
+    }
+    // members PlanManager calls that have no device side: rosparam loading (set the public members instead), the A* handle, RViz output
+    template <class NodeHandle> void init(NodeHandle&) {}
+    template <class FrontendPtr> void setFrontend(const FrontendPtr&) {}
+    void visSE2Traj(const SE2Trajectory&) {}
+    void visSE3Traj(const SE2Trajectory&) {}
 
 private:
     UnevenMapHandle* env_ = nullptr;

@@ -54,20 +54,68 @@ def test_product_does_not_import_the_oracle():
                 assert "oracle_py" not in txt and "liboracle" not in txt and '"../../oracle' not in txt, f
 
 
-def test_cpp_adapter_compiles(tmp_path):
-    """the header-only adapter (same member names as the reference's ALMTrajOpt) compiles as plain C++17 against the C-ABI header"""
-    import subprocess
-    src = tmp_path / "use_adapter.cpp"
-    src.write_text('''
+CONSUMER = r"""
+// What a goal callback does with the back-end (the call sequence of plan_manager/src/plan_manager.cpp:17-22 and 134-185, written
+// against the adapter; Eigen is not installed in this image, so Eigen::Vector2d / VectorXd are aliases of the adapter's stand-in)
+#include <cstdio>
 #include "uneven_hip_adapter.hpp"
-int run(uneven_hip::UnevenMapHandle& map) {
-    uneven_hip::ALMTrajOpt opt;
-    opt.max_vel = 0.5;
-    opt.setEnvironment(&map);
-    uneven_hip::Mat init_xy(2, 3), end_xy(2, 3), inner_xy(2, 4), init_yaw(3, 1), end_yaw(3, 1), inner_yaw(9, 1);
-    int rc = opt.optimizeSE2Traj(init_xy, end_xy, inner_xy, init_yaw, end_yaw, inner_yaw, 3.0);
-    uneven_hip::SE2Trajectory t = opt.getTraj();
-    return rc + (int)t.pos_traj.size() + (opt.getTrajJerkCost() > 0);
+namespace Eigen { using Vector2d = uneven_hip::VecN<2>; using VectorXd = uneven_hip::VecN<1>; }
+struct FakeNodeHandle {};
+struct FakeFrontend {};
+using namespace uneven_hip;
+
+int plan_once(UnevenMapHandle& map, const Mat& init_xy, const Mat& end_xy, const Mat& inner_xy, const Mat& init_yaw, const Mat& end_yaw,
+              const Mat& inner_yaw, double total_time, SE2TrajMsg& traj_msg, std::vector<double>& report) {
+    FakeNodeHandle nh;
+    FakeFrontend* astar = nullptr;
+    ALMTrajOpt traj_opt;
+    traj_opt.init(nh);
+    traj_opt.setFrontend(astar);
+    traj_opt.setEnvironment(&map);
+    const int rc = traj_opt.optimizeSE2Traj(init_xy, end_xy, inner_xy, init_yaw, end_yaw, inner_yaw, total_time);
+    SE2Trajectory back_end_traj = traj_opt.getTraj();
+    traj_opt.visSE2Traj(back_end_traj);
+    traj_opt.visSE3Traj(back_end_traj);
+    std::vector<double> max_terrain_value = traj_opt.getMaxVxAxAyCurAttSig(back_end_traj);
+    report = max_terrain_value;
+    report.push_back(back_end_traj.getNonHolError());
+    std::printf("equal error %g max vx %g min cosxi %g\n", back_end_traj.getNonHolError(), max_terrain_value[0], -max_terrain_value[4]);
+    // the message the MPC node receives: piece start points + end point, piece durations
+    for (int i = 0; i < back_end_traj.pos_traj.getPieceNum(); i++) {
+        Point3 pospt;
+        Eigen::Vector2d pos = back_end_traj.pos_traj[i].getValue(0.0);
+        pospt.x = pos[0]; pospt.y = pos[1];
+        traj_msg.pos_pts.push_back(pospt);
+        traj_msg.posT_pts.push_back(back_end_traj.pos_traj[i].getDuration());
+    }
+    Point3 pospt;
+    Eigen::Vector2d pos = back_end_traj.pos_traj.getValue(back_end_traj.pos_traj.getTotalDuration());
+    pospt.x = pos[0]; pospt.y = pos[1];
+    traj_msg.pos_pts.push_back(pospt);
+    for (int i = 0; i < back_end_traj.yaw_traj.getPieceNum(); i++) {
+        Point3 anglept;
+        Eigen::VectorXd angle = back_end_traj.yaw_traj[i].getValue(0.0);
+        anglept.x = angle[0];
+        traj_msg.angle_pts.push_back(anglept);
+        traj_msg.angleT_pts.push_back(back_end_traj.yaw_traj[i].getDuration());
+    }
+    Point3 anglept;
+    Eigen::VectorXd angle = back_end_traj.yaw_traj.getValue(back_end_traj.yaw_traj.getTotalDuration());
+    anglept.x = angle[0];
+    traj_msg.angle_pts.push_back(anglept);
+    // ... which is what the adapter's own filler produces
+    SE2TrajMsg m2;
+    fillSE2TrajMsg(back_end_traj, m2);
+    if (m2.pos_pts.size() != traj_msg.pos_pts.size() || m2.angleT_pts.size() != traj_msg.angleT_pts.size()) return -100;
+    return rc + (traj_opt.getTrajJerkCost() > 0 ? 0 : 10);
 }
-''')
-    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "a.o")])
+"""
+
+
+def test_cpp_adapter_compiles(tmp_path):
+    """the header-only adapter offers every member the goal callback calls on ALMTrajOpt / SE2Trajectory and compiles as plain C++17
+    against the C-ABI header (the GPU tier builds and RUNS the same consumer: tests/test_gpu_adapter.py)"""
+    import subprocess
+    src = tmp_path / "consumer.cpp"
+    src.write_text(CONSUMER)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "a.o")])

@@ -35,18 +35,56 @@ class SE2Traj:
     def getTotalDuration(self):
         return min(self.pos_durations.sum(), self.yaw_durations.sum())
 
-    def waypoints(self):
-        """pos_pts / angle_pts of the mpc_controller/SE2Traj message (plan_manager.cpp:159-182): piece start points + end point."""
+    @staticmethod
+    def _locate(durs, t):
+        """PolyTrajectory::locatePieceIdx (se2traj.hpp:343-361)"""
+        idx = 0
+        while idx < len(durs) and t > durs[idx]:
+            t -= durs[idx]
+            idx += 1
+        if idx == len(durs):
+            idx -= 1
+            t += durs[idx]
+        return idx, t
+
+    @staticmethod
+    def _value(c_desc, t):
+        """Piece::getValue (se2traj.hpp:106-116): coefficients highest order first, value += tn * coeff, tn *= t"""
+        v, tn = 0.0, 1.0
+        for i in range(5, -1, -1):
+            v += tn * c_desc[i]
+            tn *= t
+        return v
+
+    def getValue(self, t, yaw=False):
+        durs = self.yaw_durations if yaw else self.pos_durations
+        co = self.yaw_coeffs if yaw else self.pos_coeffs
+        total = 0.0
+        for d_ in durs:                                  # getTotalDuration's running sum (se2traj.hpp:290-299)
+            total += d_
+        idx, tl = self._locate(list(durs), total if t is None else t)
+        return np.array([self._value(co[idx, d], tl) for d in range(co.shape[1])])
+
+    def to_msg(self):
+        """the mpc_controller/SE2Traj message PlanManager publishes (mpc_controller/msg/SE2Traj.msg:1-9, filled as at
+        plan_manager.cpp:150-182): pos_pts / angle_pts = piece start points + the end point (geometry_msgs/Point: x, y, z),
+        posT_pts / angleT_pts = piece durations, init_v = init_a = 0.  start_time is the caller's (ros::Time::now())."""
         nxy, nyaw = self.pos_durations.size, self.yaw_durations.size
-        c = self.c_xy.reshape(nxy, 6, 2)
-        pts = [c[i, 0] for i in range(nxy)]
-        T = self.T_xy
-        pts.append(sum(c[-1, k] * T ** k for k in range(6)))
-        cy = self.c_yaw.reshape(nyaw, 6)
-        ang = [cy[i, 0] for i in range(nyaw)]
-        Ty = self.T_yaw
-        ang.append(sum(cy[-1, k] * Ty ** k for k in range(6)))
-        return np.array(pts), np.array(ang)
+        pos = np.zeros((nxy + 1, 3))
+        for i in range(nxy):
+            pos[i, 0], pos[i, 1] = self._value(self.pos_coeffs[i, 0], 0.0), self._value(self.pos_coeffs[i, 1], 0.0)
+        pos[nxy, :2] = self.getValue(None)
+        ang = np.zeros((nyaw + 1, 3))
+        for i in range(nyaw):
+            ang[i, 0] = self._value(self.yaw_coeffs[i, 0], 0.0)
+        ang[nyaw, 0] = self.getValue(None, yaw=True)[0]
+        return dict(pos_pts=pos, angle_pts=ang, init_v=np.zeros(3), init_a=np.zeros(3), posT_pts=self.pos_durations.copy(),
+                    angleT_pts=self.yaw_durations.copy())
+
+    def waypoints(self):
+        """pos_pts (x, y) / angle_pts of the message"""
+        m = self.to_msg()
+        return m["pos_pts"][:, :2], m["angle_pts"][:, 0]
 
 
 class ALMTrajOpt:
