@@ -25,16 +25,22 @@ BYTES_PER_SAMPLE_EVAL = 47 * 8      # 24 s gather + 14 s duals/sca
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def pmc_traffic(batch):
-    """HBM bytes per solve-kernel launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
-    tools/profile.sh): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-counts wide coalesced reads by 2x
-    (MI355X_MICROARCH.md, HBM section), so it is doubled.  None when no PMC summary for this batch size is committed."""
+def pmc_traffic(batch, stream_bytes):
+    """HBM-side bytes per solve step from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by tools/profile.sh;
+    separate --pmc passes for FETCH_SIZE and WRITE_SIZE, both in KiB).  Calibration on known-byte microkernels in THIS kernel's
+    access patterns (tools/micro/fetch_calib.hip, profiles/r02a_fetch_calibration.txt): contiguous reads -- 16-byte/lane rows and
+    8-byte/lane streams alike -- are counted at exactly 1/2, an 8-byte random gather at 64 B per access (= the line it pulls),
+    writes at 1.  The solve kernel's contiguous reads are the L-BFGS history rows and the per-sample duals / scales
+    (`stream_bytes`, algorithmic): their uncounted half is added back; gathers and writes are taken as counted.
+    None when no PMC summary for this batch size is committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
         if int(t["batch"]) != int(batch):
             return None
-        return (2.0 * t["fetch_kib"] + t["write_kib"]) * 1024.0 / max(1, t["launches"])
+        fetch = t["fetch_kib"] * 1024.0 / max(1, t["launches"])
+        write = t["write_kib"] * 1024.0 / max(1, t["launches"])
+        return fetch + min(fetch, 0.5 * stream_bytes) + write
     except Exception:
         return None
 
@@ -47,6 +53,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="trajectories per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU oracle for cpu_baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the penalty-kernel and small-batch measurements (profiling runs)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = automatic: 128 for large batches)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="also time the CPU oracle with this many threads (one trajectory per thread; context only)")
     args = ap.parse_args()
@@ -104,6 +111,41 @@ def main():
     single_ms = sst["kernel_ms"] + sst["prepare_ms"]
     single_ms_per_iter = sst["kernel_ms"] / max(1, sst["lbfgs_iters"])
     del single
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        # BASELINE configs[1]: the penalty kernel alone (uph_eval_batch: `repeat` objective+gradient evaluations per trajectory inside
+        # one launch), on the hill trajectory x 256 and on the whole batch; algorithmic bytes = samples x 376 B
+        R = 20
+        pk = {}
+        for tag, pp in (("hill_x256", [scenes.hill_problem()] * 256), ("batch", probs)):
+            ev = U.ALMTrajOpt(m)
+            if args.lanes:
+                ev.set_lanes(args.lanes)
+            ev.upload(pp)
+            ev.init_scaling_batch()
+            ev.eval_batch(None, repeat=R)
+            ev.eval_batch(None, repeat=R)
+            ms = ev.stats()["kernel_ms"]
+            S = sum(s_["S"] for s_ in ev._sizes)
+            gbs = S * R * BYTES_PER_SAMPLE_EVAL / (ms * 1e-3) / 1e9
+            pk[tag] = {"trajectories": len(pp), "evals_per_launch": R, "kernel_ms": ms, "us_per_traj_eval": ms * 1e3 / R,
+                       "M_traj_evals_per_s": len(pp) * R / ms / 1e3, "samples_per_traj": S / len(pp), "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
+            del ev
+        extras["penalty_kernel"] = pk
+        # the batch sizes BASELINE.json names (configs[2]: 256, configs[4]: 4096), same scene and protocol, one warm-up + three solves each
+        for Bx in (256, 4096):
+            if Bx >= args.batch:
+                continue
+            o2 = U.ALMTrajOpt(m)
+            o2.upload(probs[:Bx])
+            o2.set_rho(1.0); o2.solve()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                o2.set_rho(1.0); o2.solve()
+            torch.cuda.synchronize()
+            extras["traj_opts_per_s_B%d" % Bx] = Bx * 3 / (time.perf_counter() - t1)
+            del o2
     opt.upload(probs)
 
     kernel_ms, prepare_ms, evals, sample_evals, iters, hist_bytes = [], [], 0, 0, 0, 0
@@ -147,10 +189,11 @@ def main():
             "scaling_kernel_ms": float(np.mean(prepare_ms)),
             "converged_frac": float((rets == 0).mean()), "map_build_s": map_build_s, "map_kernel_ms": map_stats["kernel_ms"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.batch), "kernel": "uph_solver_kernel<%s,2> (ALM/L-BFGS solve)" % ("128,2" if args.batch >= 2304 else ("256,2" if args.batch >= 512 else "256,1")), "avg_launch_ms": avg_ms,
+                         "traffic": pmc_traffic(args.batch, hist_bytes / K + sample_evals * 14 * 8 / K), "kernel": "uph_solver_kernel<%s,2> (ALM/L-BFGS solve)" % ("128,2" if args.batch >= 2304 else ("256,2" if args.batch >= 512 else "256,1")), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "sample_bytes_per_launch": sample_evals * BYTES_PER_SAMPLE_EVAL / K, "history_bytes_per_launch": hist_bytes / K},
         }
+        res.update(extras)
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:
             from oracle import oracle_py as O
             og = O.OracleGrid()

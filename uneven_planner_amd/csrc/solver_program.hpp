@@ -78,7 +78,7 @@ struct Solver {
         recd = recd < adj ? adj : recd;
         recd = recd < (size_t)mem ? (size_t)mem : recd;                  // ... and the two-loop's alphas
         const size_t td_ = (size_t)Nxy + K + 2;                          // sample-time tables; gamma lives in the same words after adjoint()
-        return (size_t)5 * n + (nvec < td_ ? td_ : nvec) + 2 * (12 * Nxy + 6 * Nyaw) + recd + (size_t)18 * (K + 1) + THOMAS_DOUBLES + MAX_PAST + 8 + 18;
+        return (size_t)5 * n + (nvec < td_ ? td_ : nvec) + 2 * (12 * Nxy + 6 * Nyaw) + recd + (size_t)6 * (K + 1) + THOMAS_DOUBLES + MAX_PAST + 8 + 18;
     }
 
     UPH_HD Solver(WG& w, const GridDev& gr, const OptParams& p, const BatchDev& b, int bi, double* lds)
@@ -98,7 +98,7 @@ struct Solver {
         q += nvec < Nxy + K + 2 ? Nxy + K + 2 : nvec;
         cxy = q; q += 12 * Nxy; cyaw = q; q += 6 * Nyaw;
         Gxy = q; q += 12 * Nxy; Gyaw = q; q += 6 * Nyaw;
-        wtab = q; q += 18 * (K + 1);                         // basis weights of the K + 1 in-piece sample times: [j][k][beta0, beta1, beta2]
+        wtab = q; q += 6 * (K + 1);                          // powers s1^0 .. s1^5 of the K + 1 in-piece sample times: [j][k]
         rec = q;                                             // (wtab sits right before rec: scatterChunk's unmasked batch reads may run past either one's end by a few words)
         {
             size_t rd = (size_t)recd;
@@ -343,8 +343,9 @@ struct Solver {
     UPH_HD double augGrad(double h, double lm) const { return rho * h + lm; }
 
     // What the sample leaves for the per-piece reduction (alm_traj_opt.cpp:969-979):
-    //   rec[0..5]  = grad_p, grad_v, grad_a (2 each): scatterChunk applies the basis weights beta0/1/2 of the sample's in-piece time,
-    //                which depend on j only and are tabulated once per evaluation (wtab, written by the 17 samples of piece 0)
+    //   rec[0..5]  = grad_p, grad_v, grad_a (2 each): scatterChunk applies the basis weights beta0/1/2 of the sample's in-piece time
+    //                (beta0_k = s1^k, beta1_k = k s1^(k-1), beta2_k = k (k-1) s1^(k-2)), which depend on j only: the powers are
+    //                tabulated once per evaluation (wtab, written by the 17 samples of piece 0)
     //   rec[6+k]   = beta0_k(u) grad_yaw + beta1_k(u) grad_dyaw   -> gdCyaw block of its yaw piece (grad_d2yaw == 0, Q8)
     //   rtag       = that yaw piece (int32)
     UPH_HD void putRec(int slot, int i, int j, const double gp_[2], const double gv_[2], const double ga_[2], double gyaw, double gdyaw, const Kin& k) {
@@ -359,15 +360,10 @@ struct Solver {
         rec[10 * CHP + slot] = (u4 * gyaw + 4.0 * u3 * gdyaw);
         rec[11 * CHP + slot] = (u5 * gyaw + 5.0 * u4 * gdyaw);
         rtag[slot] = k.yaw_idx;
-        if (i == 0) {                                    // beta0/1/2 of alm_traj_opt.cpp:738-740 at s1(j), rebuilt from s1 (not kept live across the sample)
-            double* w = wtab + 18 * j;
+        if (i == 0) {                                    // the powers behind beta0/1/2 of alm_traj_opt.cpp:738-740 at s1(j) (rebuilt from s1: not kept live across the sample)
+            double* w = wtab + 6 * j;
             const double s1 = k.s1, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
-            w[0] = 1.0; w[1] = 0.0; w[2] = 0.0;
-            w[3] = s1; w[4] = 1.0; w[5] = 0.0;
-            w[6] = s2; w[7] = 2.0 * s1; w[8] = 2.0;
-            w[9] = s3; w[10] = 3.0 * s2; w[11] = 6.0 * s1;
-            w[12] = s4; w[13] = 4.0 * s3; w[14] = 12.0 * s2;
-            w[15] = s5; w[16] = 5.0 * s4; w[17] = 20.0 * s3;
+            w[0] = 1.0; w[1] = s1; w[2] = s2; w[3] = s3; w[4] = s4; w[5] = s5;
         }
     }
 
@@ -574,17 +570,19 @@ struct Solver {
                 // every operand of a batch is read at base + constant (no per-element clamping or address arithmetic); reads past the
                 // piece's last slot land in neighbouring LDS words of the same allocation and are discarded by the selects below
                 const double* r0 = rec + dd * CHP + ja;      // grad_p[dd]; grad_v[dd] two rows on, grad_a[dd] four
-                const double* w = wtab + 3 * q + 18 * (ja - jo);
+                const double* w = wtab + 6 * (ja - jo);      // powers of s1(j) at w[6 * (slot - ja) + k]
+                const int q1 = q >= 1 ? q - 1 : 0, q2 = q >= 2 ? q - 2 : 0;
+                const double c1 = (double)q, c2 = (double)(q * (q - 1));      // beta1_q = q s1^(q-1), beta2_q = q (q-1) s1^(q-2)
                 double a = 0.0;
-                for (int len = jb - ja; len > 0; len -= UPH_SC_XB, r0 += UPH_SC_XB, w += 18 * UPH_SC_XB) {
+                for (int len = jb - ja; len > 0; len -= UPH_SC_XB, r0 += UPH_SC_XB, w += 6 * UPH_SC_XB) {
                     double e0[UPH_SC_XB], e1[UPH_SC_XB], e2[UPH_SC_XB], w0[UPH_SC_XB], w1[UPH_SC_XB], w2[UPH_SC_XB];
 #pragma unroll
                     for (int u = 0; u < UPH_SC_XB; u++) {
                         e0[u] = r0[u]; e1[u] = r0[2 * CHP + u]; e2[u] = r0[4 * CHP + u];
-                        w0[u] = w[18 * u]; w1[u] = w[18 * u + 1]; w2[u] = w[18 * u + 2];
+                        w0[u] = w[6 * u + q]; w1[u] = w[6 * u + q1]; w2[u] = w[6 * u + q2];
                     }
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_XB; u++) a += u < len ? (w0[u] * e0[u] + w1[u] * e1[u] + w2[u] * e2[u]) : 0.0;
+                    for (int u = 0; u < UPH_SC_XB; u++) a += u < len ? (w0[u] * e0[u] + (c1 * w1[u]) * e1[u] + (c2 * w2[u]) * e2[u]) : 0.0;
                 }
                 Gxy[12 * i + r] += a;
             } else {
