@@ -146,7 +146,7 @@ static double *g_hg = nullptr, *g_hd = nullptr, *g_hpf = nullptr, *g_hs = nullpt
 
 struct Emu {
     GridDev grid;
-    std::vector<double> sigma, zbx, zby, z;
+    std::vector<double> sigma, zbx, zby, z, cells;
     OptParams P;
 };
 
@@ -165,7 +165,8 @@ void* emu_create(const double* mp11, const double* cells4, const double* op21) {
     size_t nc = (size_t)g.nx * g.ny * g.nyaw;
     e->sigma.resize(nc); e->zbx.resize(nc); e->zby.resize(nc); e->z.resize(nc);
     for (size_t i = 0; i < nc; i++) { e->z[i] = cells4[4 * i]; e->sigma[i] = cells4[4 * i + 1]; e->zbx[i] = cells4[4 * i + 2]; e->zby[i] = cells4[4 * i + 3]; }
-    g.sigma = e->sigma.data(); g.zbx = e->zbx.data(); g.zby = e->zby.data(); g.z = e->z.data();
+    e->cells.assign(cells4, cells4 + 4 * nc);
+    g.sigma = e->sigma.data(); g.zbx = e->zbx.data(); g.zby = e->zby.data(); g.z = e->z.data(); g.cells = e->cells.data();
     OptParams& P = e->P;
     P.rho_T = op21[0]; P.rho_ter = op21[1]; P.max_vel = op21[2]; P.max_acc_lon = op21[3]; P.max_acc_lat = op21[4];
     P.max_kap = op21[5]; P.min_cxi = op21[6]; P.max_sig = op21[7]; P.use_scaling = op21[8] != 0.0;

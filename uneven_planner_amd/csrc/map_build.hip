@@ -402,6 +402,7 @@ int uph_map_create(const uph_map_params* mp, int device, uph_map** out) {
     HIPCHK(hipMalloc((void**)&m->d_occ2, (size_t)g.nx * g.ny));
     HIPCHK(hipMemset(m->d_cells, 0, m->ncell * 4 * sizeof(double)));                 // map_buffer = RXS2() zeros (:118)
     g.sigma = m->d_planes; g.zbx = m->d_planes + m->ncell; g.zby = m->d_planes + 2 * m->ncell; g.z = m->d_planes + 3 * m->ncell;
+    g.cells = m->d_cells;
     int r = commitMap(m);
     if (r != UPH_OK) { delete m; return r; }
     *out = m;

@@ -168,6 +168,64 @@ UPH_HD void terrainBase(const GridDev& g, double x, double y, double yaw, double
     for (int k = 0; k < 3; k++) { gs[k] = grd[0][k]; gzx[k] = grd[1][k]; gzy[k] = grd[2][k]; }
 }
 
+// The same base quantities from the array-of-cells form of the grid (GridDev::cells: {z, sigma, zb.x, zb.y} per cell, the reference's
+// own RXS2 order, uneven_map.h:36-64, 427-435): a cell is 32 bytes, so one corner is two 16-byte loads and the eight corners of a
+// sample are 16 loads on 8 addresses (24 8-byte loads on 24 addresses in the three-plane form).  One yaw slice at a time: the
+// bilinear values and the x / y partial sums of a slice need only that slice's four cells; the two slices meet in the last lerp.
+// Same operations and order as interpField (uneven_map.h:297-311).
+UPH_HD void terrainBaseCells(const GridDev& g, double x, double y, double yaw, double& sg, double& zx, double& zy, double gs[3], double gzx[3], double gzy[3]) {
+    Corners c;
+    locate(g, x, y, yaw, c);
+    sg = zx = zy = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { gs[k] = 0.0; gzx[k] = 0.0; gzy[k] = 0.0; }
+    if (!c.inmap) return;                                   // out of map: zeros (uneven_map.h:260-265)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef double dbl2_t __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) dbl2_t* cellp;
+#else
+    struct dbl2_t { double x, y; };
+    typedef const dbl2_t* cellp;
+#endif
+    const double dx = c.dx, dy = c.dy, dw = c.dyaw;
+    double v0[3], v1[3], gy0[3], gy1[3], gx0[3], gx1[3];      // per yaw slice: bilinear value, (v1x - v0x) blends for d/dy and d/dx
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        const int wi = w == 0 ? c.w0 : c.w1;
+        double f[2][2][3];                                  // [a][b][sigma, zb.x, zb.y]
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const cellp p = (cellp)(g.cells + 4 * (c.a[a][b] + wi));
+                const dbl2_t lo = p[0], hi = p[1];          // (z, sigma), (zb.x, zb.y)
+                f[a][b][0] = lo.y; f[a][b][1] = hi.x; f[a][b][2] = hi.y;
+            }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double vy0 = f[0][0][k] * (1 - dx) + f[1][0][k] * dx;       // v00 / v01 of uneven_map.h:297-300
+            const double vy1 = f[0][1][k] * (1 - dx) + f[1][1][k] * dx;       // v10 / v11
+            const double vv = vy0 * (1 - dy) + vy1 * dy;
+            const double gyv = vy1 - vy0;
+            const double gxa = f[1][0][k] - f[0][0][k], gxb = f[1][1][k] - f[0][1][k];
+            if (w == 0) { v0[k] = vv; gy0[k] = gyv; gx0[k] = (1 - dw) * (1 - dy) * gxa; gx0[k] += (1 - dw) * dy * gxb; }
+            else { v1[k] = vv; gy1[k] = gyv; gx1[k] = dw * (1 - dy) * gxa; gx1[k] += dw * dy * gxb; }
+        }
+    }
+    const double xi = g.xy_inv, wi_ = g.yaw_inv;
+    double val[3], grd[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        val[k] = v0[k] * (1 - dw) + v1[k] * dw;
+        grd[k][2] = (v1[k] - v0[k]) * wi_;
+        grd[k][1] = (gy0[k] * (1 - dw) + gy1[k] * dw) * xi;
+        grd[k][0] = (gx0[k] + gx1[k]) * xi;
+    }
+    sg = val[0]; zx = val[1]; zy = val[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { gs[k] = grd[0][k]; gzx[k] = grd[1][k]; gzy[k] = grd[2][k]; }
+}
+
 // value-only variant: getTerrain + getTerrainVariables (uneven_map.h:154-201, 221-256).  zout = interpolated z
 UPH_HD void terrainVariables(const GridDev& g, double x, double y, double yaw, double cyaw, double syaw, double values[7], double* zout) {
     Corners c;

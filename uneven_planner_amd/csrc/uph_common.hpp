@@ -75,6 +75,7 @@ struct GridDev {
     const double* zbx;
     const double* zby;
     const double* z;
+    const double* cells;          // array-of-cells form {z, sigma, zb.x, zb.y} (the build output, uneven_map.h:36-64 order): what the penalty kernel gathers
 };
 
 // Optimiser parameters (alm_traj_opt.h:29-53) + L-BFGS defaults the reference does not override (lbfgs.hpp:76-128)
