@@ -50,13 +50,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8192, help="trajectories per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU per step (hill, default 8192) / in total (km2, default 4096)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU oracle for cpu_baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the penalty-kernel and small-batch measurements (profiling runs)")
+    ap.add_argument("--workload", choices=("hill", "km2"), default="hill",
+                    help="hill: the BASELINE metric's scene (default).  km2: configs[4] -- analytic 1 km^2 fractal terrain in fp32 cells, --batch (default 4096) "
+                         "local-goal solves in total, split over the ranks (strong scaling)")
+    ap.add_argument("--map-size", type=float, default=1000.0, help="km2 workload: side of the square map [m]")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = automatic: 128 for large batches)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="also time the CPU oracle with this many threads (one trajectory per thread; context only)")
     args = ap.parse_args()
+    km2 = args.workload == "km2"
+    if not args.batch:
+        args.batch = 4096 if km2 else 8192
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -74,21 +81,38 @@ def main():
     import uneven_planner_amd as U
     from uneven_planner_amd import scenes
 
-    # ---- map: hill cloud -> SE(2) grid on the device (not timed).  N > 1: x-slabs + one RCCL all-gather
-    xyz = scenes.make_hill_cloud()
-    m = U.UnevenMap(device=device)
+    # ---- map on the device (not timed).  N > 1: x-slabs + one RCCL all-gather
+    gather = lambda full, slab: dist.all_gather_into_tensor(full, slab)
     t0 = time.time()
-    if distributed and int(m.voxel_num[0]) % world == 0:
-        m.build_sharded(xyz, rank, world, lambda full, slab: dist.all_gather_into_tensor(full, slab))
+    if km2:
+        # configs[4]: analytic fractal terrain, fp32 cells (16 bytes per cell; 1 km^2 at 0.25 m x 64 yaw bins = 16.4 GB, replicated per GPU)
+        from uneven_planner_amd.uneven_map import KM2_MAP_PARAMS
+        m = U.UnevenMap(dict(KM2_MAP_PARAMS, map_size_x=args.map_size, map_size_y=args.map_size), device=device, storage="f32")
+        if distributed:
+            m.fill_fbm_sharded(None, rank, world, gather)
+        else:
+            m.fill_fbm()
     else:
-        m.build(xyz)
+        xyz = scenes.make_hill_cloud()      # hill cloud -> SE(2) grid by the plane-fit kernel
+        m = U.UnevenMap(device=device)
+        if distributed and int(m.voxel_num[0]) % world == 0:
+            m.build_sharded(xyz, rank, world, gather)
+        else:
+            m.build(xyz)
     map_build_s = time.time() - t0
     map_stats = m.build_stats()
 
-    # ---- problems: config-3 protocol on the hill map, free cells only
+    # ---- problems, free cells only: config-3 protocol on the hill map; local goals (4..14 m) over the whole square for km2
     nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
-    probs = scenes.random_problems(args.batch, seed0=1000 + rank * args.batch, occ_r2=m.occ_r2_buffer,
-                                   grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
+    gridinfo = (nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1])
+    if km2:
+        total_batch = args.batch
+        lo, args.batch = scenes.batch_share(total_batch, rank, world)      # this rank's share of the one batch (strong scaling)
+        if args.batch < 1:
+            raise SystemExit("km2: batch of %d cannot be split over %d ranks" % (total_batch, world))
+        probs = scenes.local_problems(args.batch, seed0=5000 + lo, half=0.5 * args.map_size - 5.0, occ_r2=m.occ_r2_buffer, grid=gridinfo)
+    else:
+        probs = scenes.random_problems(args.batch, seed0=1000 + rank * args.batch, occ_r2=m.occ_r2_buffer, grid=gridinfo)
     opt = U.ALMTrajOpt(m)
     if args.lanes:
         opt.set_lanes(args.lanes)
@@ -104,7 +128,7 @@ def main():
         opt.solve()
     # single-trajectory latency on the hill problem of configs[0]/[1] (not part of the timed region)
     single = U.ALMTrajOpt(m)
-    single.upload([scenes.hill_problem()])
+    single.upload([probs[0] if km2 else scenes.hill_problem()])
     single.set_rho(1.0); single.solve()
     single.set_rho(1.0); single.solve()
     sst = single.stats()
@@ -112,7 +136,7 @@ def main():
     single_ms_per_iter = sst["kernel_ms"] / max(1, sst["lbfgs_iters"])
     del single
     extras = {}
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and not km2:
         # BASELINE configs[1]: the penalty kernel alone (uph_eval_batch: `repeat` objective+gradient evaluations per trajectory inside
         # one launch), on the hill trajectory x 256 and on the whole batch; algorithmic bytes = samples x 376 B
         R = 20
@@ -169,19 +193,23 @@ def main():
 
     if rank == 0:
         K = args.steps
-        total = args.batch * world * K
+        total = (total_batch if km2 else args.batch * world) * K
         value = total / dt
+        # km2: the gather reads fp32 cells (24 x 4 B per sample); duals, scales, residuals and coefficients stay fp64 (23 x 8 B)
+        bytes_per_sample = (24 * 4 + 23 * 8) if km2 else BYTES_PER_SAMPLE_EVAL
         # roofline of the dominant kernel (per launch, rank 0): algorithmic bytes / HIP-event duration
         n_sum = sum(s["n"] for s in opt._sizes)
-        per_launch_bytes = (sample_evals * BYTES_PER_SAMPLE_EVAL + hist_bytes + iters * 2 * 8 * (n_sum / max(1, args.batch))) / K
+        per_launch_bytes = (sample_evals * bytes_per_sample + hist_bytes + iters * 2 * 8 * (n_sum / max(1, args.batch))) / K
         avg_ms = float(np.mean(kernel_ms))
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         res = {
             "metric": "MINCO traj-opts/sec (batch)", "value": value, "unit": "traj-opts/s", "n_gpus": world, "steps": K,
-            "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if km2 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "hill scene (synthetic hill cloud, map built on device), batch of %d random start/goal "
-                                   "full ALM solves per GPU (configs[1] scene, configs[2] start/goal protocol), run_hill.yaml params" % args.batch,
+            "config": {"workload": ("configs[4]: analytic fractal terrain %.0f m x %.0f m (fBm H 0.8, seed 7), fp32 cell storage with fp64 arithmetic, one batch of %d "
+                                    "local-goal (4-14 m) full ALM solves split over the GPUs, run_hill.yaml params" % (args.map_size, args.map_size, total_batch)) if km2 else
+                                   ("hill scene (synthetic hill cloud, map built on device), batch of %d random start/goal "
+                                    "full ALM solves per GPU (configs[1] scene, configs[2] start/goal protocol), run_hill.yaml params" % args.batch),
                        "batch_per_gpu": args.batch, "grid": [nx, ny, int(m.voxel_num[2])], "parallelism": "dp%d" % world},
             "ms_per_lbfgs_iter": single_ms_per_iter,       # single hill trajectory alone on the GPU (configs[1]): solve kernel ms / its L-BFGS iterations
             "single_traj_ms": single_ms, "batch_lbfgs_iters_per_s": iters / dt,
@@ -189,26 +217,30 @@ def main():
             "scaling_kernel_ms": float(np.mean(prepare_ms)),
             "converged_frac": float((rets == 0).mean()), "map_build_s": map_build_s, "map_kernel_ms": map_stats["kernel_ms"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.batch, hist_bytes / K + sample_evals * 14 * 8 / K), "kernel": "uph_solver_kernel<%s,2> (ALM/L-BFGS solve)" % ("128,2" if args.batch >= 2304 else ("256,2" if args.batch >= 512 else "256,1")), "avg_launch_ms": avg_ms,
+                         "traffic": None if km2 else pmc_traffic(args.batch, hist_bytes / K + sample_evals * 14 * 8 / K), "kernel": "uph_solver_kernel<%s,2> (ALM/L-BFGS solve)" % ("128,2" if args.batch >= 2304 else ("256,2" if args.batch >= 512 else "256,1")), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "sample_bytes_per_launch": sample_evals * BYTES_PER_SAMPLE_EVAL / K, "history_bytes_per_launch": hist_bytes / K},
+                         "sample_bytes_per_launch": sample_evals * bytes_per_sample / K, "history_bytes_per_launch": hist_bytes / K},
         }
         res.update(extras)
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:
             from oracle import oracle_py as O
-            og = O.OracleGrid()
-            og.set_cells(m.map_buffer)
             nsamp = min(args.cpu_sample, len(probs))
-            t0 = time.perf_counter()
-            c_iters = 0
+            if not km2:
+                og = O.OracleGrid()
+                og.set_cells(m.map_buffer)
+            cdt, c_iters = 0.0, 0
             for p in probs[:nsamp]:
-                r = O.OracleALM(og).optimize(p)
+                # km2: the 1e9-cell grid stays on the device; the problem is solved on the window of cells around it, translated by whole
+                # cells (window download not timed)
+                g_, q_ = O.window_oracle(m, p)[:2] if km2 else (og, p)
+                t0 = time.perf_counter()
+                r = O.OracleALM(g_).optimize(q_)
+                cdt += time.perf_counter() - t0
                 c_iters += r["lbfgs_iters"]
-            cdt = time.perf_counter() - t0
             res["cpu_baseline"] = {"value": nsamp / cdt, "unit": "traj-opts/s", "cores": 1, "kind": "port",
                                    "sample": "first %d problems of the same batch, CPU oracle (C++ -O3, single thread), %.1f s" % (nsamp, cdt),
                                    "ms_per_lbfgs_iter": cdt * 1e3 / max(1, c_iters), "host_cpus": os.cpu_count()}
-            if args.cpu_threads > 1:
+            if args.cpu_threads > 1 and not km2:
                 # context only: the reference is single-threaded; this is "one trajectory per host thread" on the same box
                 from concurrent.futures import ThreadPoolExecutor
                 nmt = min(len(probs), max(nsamp, 8 * args.cpu_threads))

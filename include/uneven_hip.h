@@ -64,6 +64,24 @@ typedef struct uph_map_params {
     double gravity;             /* 9.81  */
 } uph_map_params;
 
+/* ---- analytic fractal terrain of BASELINE.json configs[4] ("synthetic 1 km^2 fractal terrain ... fp32").  No reference
+ *      counterpart: the reference only loads .pcd clouds (uneven_map.cpp:121-128); the cell fit applied to the analytic surface is
+ *      constructMap's (uneven_map.cpp:329-391).  Values of tools / bench: seed 7, H 0.8, 2..512 m, 15 m, 35 deg, 32 waves */
+#define UPH_FBM_MAX_WAVES 48
+#define UPH_FBM_TABLE_DOUBLES (4 * UPH_FBM_MAX_WAVES + 12 + 9)
+typedef struct uph_fbm_params {
+    uint64_t seed;
+    double hurst;               /* amplitude ~ wavelength^hurst                                             */
+    double lambda_min, lambda_max;   /* band limits of the fBm sum [m]                                       */
+    double amplitude;           /* bound on the sum of the wave amplitudes [m]                               */
+    double max_slope_deg;       /* bound on the sum of amplitude x wavenumber (worst-case slope)             */
+    int32_t n_waves;            /* <= UPH_FBM_MAX_WAVES                                                      */
+    double rough_amp;           /* ripple amplitude inside rough patches [m]                                 */
+    double rough_lambda;        /* ripple wavelength [m] (x 0.8..1.2)                                        */
+    double patch_lambda;        /* envelope wavelength [m] (x 1..3)                                          */
+    double rough_threshold;     /* envelope level above which ripples appear (0..1)                          */
+} uph_fbm_params;
+
 /* ---- optimiser parameters: alm_traj_opt.h:29-53, values of run_hill.yaml:32-55 */
 typedef struct uph_opt_params {
     double rho_T, rho_ter, max_vel, max_acc_lon, max_acc_lat, max_kap, min_cxi, max_sig;
@@ -114,6 +132,17 @@ const char* uph_version(void);
 
 /* ---- terrain map */
 int uph_map_create(const uph_map_params* mp, int device, uph_map** out);
+/* the same grid with its cells stored as four floats (16 bytes) instead of four doubles: BASELINE.json configs[4]'s fp32 mode.  Lookups widen
+ * to double on load and all arithmetic stays fp64; uph_map_build is refused, the cells come from uph_map_fill_fbm / uph_map_set_cells / import */
+int uph_map_create_f32(const uph_map_params* mp, int device, uph_map** out);
+int uph_map_storage_bytes(const uph_map* m);                                  /* 8 or 4: bytes per stored field */
+/* fill the x-slab [x0, x1) (x1 <= 0: whole map) with the analytic fractal terrain: one constructMap-style plane fit per cell on a 5 x 3
+ * body-frame lattice of surface samples; then commit.  uph_fbm_table returns the wave table a checker needs to restate the surface:
+ * [UPH_FBM_MAX_WAVES][a, kx, ky, phase], ripples [4][kx, ky, phase], envelope [3][kx, ky, phase] */
+int uph_map_fill_fbm(uph_map* m, const uph_fbm_params* fp, int32_t x0, int32_t x1);
+int uph_fbm_table(const uph_fbm_params* fp, double* table);
+/* cells of the xy window [x0, x1) x [y0, y1) (all yaw bins) as doubles, whatever the storage: rxs2[(x1-x0)*(y1-y0)*nyaw*4] */
+int uph_map_get_window(uph_map* m, int32_t x0, int32_t x1, int32_t y0, int32_t y1, double* rxs2);
 void uph_map_destroy(uph_map* m);
 int uph_map_dims(const uph_map* m, int32_t dims3[3]);                       /* voxel_num (uneven_map.cpp:108-110) */
 /* cells: ncell x 4 {z, sigma, zb.x, zb.y} in the reference's address order (uneven_map.h:427-435); recomputes c and occupancy */
@@ -124,7 +153,7 @@ int uph_map_get_cells(uph_map* m, double* rxs2, double* c, char* occ, char* occ_
  * xyz: n x 3 float32 (what pcl::PCDReader delivers).  Cells outside the slab are untouched.  Blocking. */
 int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x1);
 /* device pointer / byte size of the AoS cell array (ncell x 4 doubles) so that the host framework can all-gather
- * x-slabs across GPUs (RCCL) in place; call uph_map_commit afterwards to refresh the SoA planes, c and occupancy */
+ * x-slabs across GPUs (RCCL) in place; call uph_map_commit afterwards to refresh c and occupancy */
 int uph_map_cells_device(uph_map* m, void** dptr, int64_t* nbytes);
 int uph_map_commit(uph_map* m);
 /* sharded build helpers (device pointers owned by the caller, e.g. torch tensors used with torch.distributed / RCCL):

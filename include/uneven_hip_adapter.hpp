@@ -188,8 +188,10 @@ inline void fillSE2TrajMsg(const SE2Trajectory& traj, Msg& msg) {
 
 class UnevenMapHandle {            // owns a uph_map; what UnevenMap::Ptr is to the reference's optimiser
 public:
-    explicit UnevenMapHandle(const uph_map_params& mp, int device = 0) {
-        if (uph_map_create(&mp, device, &m_) != UPH_OK) throw std::runtime_error(std::string("uph_map_create: ") + uph_last_error());
+    // fp32_cells: store the cells as four floats (16 bytes) instead of four doubles -- km^2-scale grids (BASELINE.json configs[4])
+    explicit UnevenMapHandle(const uph_map_params& mp, int device = 0, bool fp32_cells = false) {
+        if ((fp32_cells ? uph_map_create_f32(&mp, device, &m_) : uph_map_create(&mp, device, &m_)) != UPH_OK)
+            throw std::runtime_error(std::string("uph_map_create: ") + uph_last_error());
     }
     ~UnevenMapHandle() { uph_map_destroy(m_); }
     UnevenMapHandle(const UnevenMapHandle&) = delete;
@@ -203,6 +205,10 @@ public:
     // UnevenMap::constructMapInput replacement: cells from the `.map` cache (ncell x 4: z, sigma, zb.x, zb.y in the reference's address order)
     void setCells(const double* rxs2) {
         if (uph_map_set_cells(m_, rxs2) != UPH_OK) throw std::runtime_error(std::string("uph_map_set_cells: ") + uph_last_error());
+    }
+    // analytic fractal terrain instead of a cloud (configs[4]; no counterpart in the reference)
+    void fillFractal(const uph_fbm_params& fp) {
+        if (uph_map_fill_fbm(m_, &fp, 0, 0) != UPH_OK) throw std::runtime_error(std::string("uph_map_fill_fbm: ") + uph_last_error());
     }
     // fills the host members of the reference's UnevenMap (map_buffer as 4 doubles per cell, c_buffer, occ_buffer, occ_r2_buffer)
     void download(double* rxs2, double* c, char* occ, char* occ_r2) { uph_map_get_cells(m_, rxs2, c, occ, occ_r2); }

@@ -437,3 +437,34 @@ def lbfgs_rosenbrock(x0, mem_size=8, past=3, g_eps=1e-5, delta=1e-6):
     it, ev = C.c_int(0), C.c_int(0)
     r = lib().orc_lbfgs_rosenbrock(x.size, _dp(x), _dp(f), mem_size, past, g_eps, delta, C.byref(it), C.byref(ev))
     return r, x, f[0], it.value, ev.value
+
+
+def window_oracle(umap, prob, margin=8.0):
+    """Checker for grids too large to copy to the host (BASELINE.json configs[4], 1e9 cells): the cells of the xy window around one
+    problem, downloaded from the device map `umap` (UnevenMap.get_window), as an OracleGrid of that window's size, and the problem
+    translated into the window's frame.  The translation is a whole number of cells, so it is exact in floating point and the
+    window grid holds the same cell values at the same relative positions; only the (x - origin) roundings inside the lookups
+    differ (~1e-13 relative).  Returns (grid, shifted problem, (sx, sy))."""
+    res = float(umap.xy_resolution)
+    nx, ny = int(umap.voxel_num[0]), int(umap.voxel_num[1])
+    pts = np.concatenate([np.asarray(prob["init_xy"])[:, :1], np.asarray(prob["end_xy"])[:, :1], np.asarray(prob["inner_xy"]).reshape(2, -1)], axis=1)
+    ox, oy = float(umap.map_origin[0]), float(umap.map_origin[1])
+    half = 0.5 * max(pts[0].max() - pts[0].min(), pts[1].max() - pts[1].min()) + margin
+    n = 2 * int(np.ceil(half / res))                      # even number of cells: the window centre is a cell corner
+    cx = int(round((0.5 * (pts[0].max() + pts[0].min()) - ox) / res))
+    cy = int(round((0.5 * (pts[1].max() + pts[1].min()) - oy) / res))
+    if n > nx or n > ny:
+        raise ValueError("window larger than the map")
+    x0, y0 = min(max(cx - n // 2, 0), nx - n), min(max(cy - n // 2, 0), ny - n)      # slide the window back inside the map near its border
+    cx, cy = x0 + n // 2, y0 + n // 2
+    cells = umap.get_window(x0, x0 + n, y0, y0 + n)
+    g = OracleGrid(size_x=n * res, size_y=n * res, xy_res=res, yaw_res=float(umap.yaw_resolution), gravity=float(umap.params["gravity"]))
+    assert g.dims[0] == n and g.dims[1] == n and g.dims[2] == int(umap.voxel_num[2]), (g.dims, n)
+    g.set_cells(cells.reshape(-1, 4))
+    sx, sy = ox + cx * res, oy + cy * res                 # window centre in map coordinates
+    q = {k: (np.array(v, dtype=np.float64).copy() if not np.isscalar(v) else v) for k, v in prob.items()}
+    q["init_xy"][0, 0] -= sx; q["init_xy"][1, 0] -= sy
+    q["end_xy"][0, 0] -= sx; q["end_xy"][1, 0] -= sy
+    if q["inner_xy"].size:
+        q["inner_xy"][0] -= sx; q["inner_xy"][1] -= sy
+    return g, q, (sx, sy)

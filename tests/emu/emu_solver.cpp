@@ -146,7 +146,8 @@ static double *g_hg = nullptr, *g_hd = nullptr, *g_hpf = nullptr, *g_hs = nullpt
 
 struct Emu {
     GridDev grid;
-    std::vector<double> sigma, zbx, zby, z, cells;
+    std::vector<double> cells;
+    std::vector<float> cells32;
     OptParams P;
 };
 
@@ -163,10 +164,8 @@ void* emu_create(const double* mp11, const double* cells4, const double* op21) {
     g.nx = (int)std::ceil(size[0] / g.xy_res); g.ny = (int)std::ceil(size[1] / g.xy_res); g.nyaw = (int)std::ceil(size[2] / g.yaw_res);
     g.gravity = mp11[10];
     size_t nc = (size_t)g.nx * g.ny * g.nyaw;
-    e->sigma.resize(nc); e->zbx.resize(nc); e->zby.resize(nc); e->z.resize(nc);
-    for (size_t i = 0; i < nc; i++) { e->z[i] = cells4[4 * i]; e->sigma[i] = cells4[4 * i + 1]; e->zbx[i] = cells4[4 * i + 2]; e->zby[i] = cells4[4 * i + 3]; }
     e->cells.assign(cells4, cells4 + 4 * nc);
-    g.sigma = e->sigma.data(); g.zbx = e->zbx.data(); g.zby = e->zby.data(); g.z = e->z.data(); g.cells = e->cells.data();
+    g.cells = e->cells.data(); g.cells32 = nullptr;
     OptParams& P = e->P;
     P.rho_T = op21[0]; P.rho_ter = op21[1]; P.max_vel = op21[2]; P.max_acc_lon = op21[3]; P.max_acc_lat = op21[4];
     P.max_kap = op21[5]; P.min_cxi = op21[6]; P.max_sig = op21[7]; P.use_scaling = op21[8] != 0.0;
@@ -178,6 +177,13 @@ void* emu_create(const double* mp11, const double* cells4, const double* op21) {
     return e;
 }
 void emu_destroy(void* h) { delete (Emu*)h; }
+// fp32 cell storage (GridDev::cells32): the cells rounded to float, read through the same lookup code
+void emu_store_f32(void* h) {
+    Emu* e = (Emu*)h;
+    e->cells32.resize(e->cells.size());
+    for (size_t i = 0; i < e->cells.size(); i++) e->cells32[i] = (float)e->cells[i];
+    e->grid.cells = nullptr; e->grid.cells32 = e->cells32.data();
+}
 void emu_set_lanes(int lanes) { g_lanes = lanes; }
 // g, d [n]; pf [8]; lm_s / lm_y [mem][n]; lm_ys [mem]; scal [8]: in step, fx, k, end, bound -> out + code, accepted, converged
 void emu_set_hook(int cap, int budget, int finish, double* g, double* d, double* pf8, double* lm_s, double* lm_y, double* lm_ys, double* scal8) {

@@ -24,6 +24,7 @@ def lib():
         L.emu_create.restype = C.c_void_p
         L.emu_create.argtypes = [dp, dp, dp]
         L.emu_destroy.argtypes = [C.c_void_p]
+        L.emu_store_f32.argtypes = [C.c_void_p]
         L.emu_terrain.argtypes = [C.c_void_p, dp, C.c_int, dp, dp]
         L.emu_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [dp] * 14 + [C.POINTER(C.c_longlong), dp]
         L.emu_minco_op.argtypes = [C.c_int, dp]
@@ -50,6 +51,11 @@ class Emu:
             self.L.emu_destroy(self.h)
         except Exception:
             pass
+
+    def store_f32(self):
+        """switch the emulated grid to fp32 cell storage (GridDev::cells32)"""
+        self.L.emu_store_f32(self.h)
+        return self
 
     def terrain(self, pos):
         pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def solve_with_fma_oracle(cells, probs, params=None):
+def solve_with_fma_oracle(cells, probs, params=None, grid_kw=None):
     from oracle import oracle_py as O
     so = "/tmp/liboracle_fma_%d.so" % os.getpid()
     subprocess.check_call(["g++", "-O3", "-march=native", "-ffp-contract=fast", "-std=c++17", "-fPIC", "-shared", "-o", so,
@@ -21,7 +21,7 @@ def solve_with_fma_oracle(cells, probs, params=None):
     real = O.os.path.join
     O.os.path.join = lambda *a, _r=real: so if a[-1] == "liboracle.so" else _r(*a)
     try:
-        g = O.OracleGrid()
+        g = O.OracleGrid(**(grid_kw or {}))
         g.set_cells(cells)
         out = [O.OracleALM(g, params).optimize(p) for p in probs]
     finally:

@@ -34,6 +34,17 @@ def _worker(rank, world, port, out_dir):
     slab = torch.zeros(per * row, dtype=torch.float64)
     slab[:(x1 - x0) * row] = torch.from_numpy(cells.reshape(nx, -1)[x0:x1].copy().ravel())
     full = gather_slabs(slab, nx, row, world, lambda f, s_: dist.all_gather_into_tensor(f, s_))
+    # fp32 storage (configs[4]): the same exchange on float slabs
+    slab32 = slab.to(torch.float32)
+    full32 = gather_slabs(slab32, nx, row, world, lambda f, s_: dist.all_gather_into_tensor(f, s_))
+    assert full32.dtype == torch.float32 and torch.equal(full32, full.to(torch.float32))
+    # strong-scaling split of one batch (bench.py --workload km2): the shares tile the batch
+    lo, cnt = scenes.batch_share(11, rank, world)
+    share = torch.tensor([lo, cnt], dtype=torch.int64)
+    shares = [torch.empty(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(shares, share)
+    covered = sorted(i for lo_, c_ in (s_.tolist() for s_ in shares) for i in range(lo_, lo_ + c_))
+    assert covered == list(range(11))
     # batch sharding: seeds 1000 + rank*B + i
     B = 3
     probs = scenes.random_problems(B, seed0=1000 + rank * B)

@@ -44,6 +44,28 @@ def test_emu_terrain_eval_scaling(emu, oracle, oracle_grid, hill_problem, small_
         assert rel(s2["scale_cx"], r2["scale_cx"]) < 1e-10
 
 
+def test_emu_f32_cell_storage_equals_oracle_on_rounded_cells(oracle, analytic_cells, hill_problem):
+    """BASELINE.json configs[4]'s fp32 mode: cells stored as floats, widened on load, fp64 arithmetic -- so the lookups and the
+    objective equal the oracle's on the float-rounded grid to rounding error, not to fp32 precision"""
+    E.lib().emu_set_lanes(128)
+    rounded = analytic_cells.astype(np.float32).astype(np.float64)
+    og = oracle.OracleGrid()
+    og.set_cells(rounded)
+    e32 = E.Emu(analytic_cells, oracle.map_params_vec(), oracle.params_vec()).store_f32()
+    rng = np.random.default_rng(2)
+    pos = np.column_stack([rng.uniform(-5.2, 5.2, 500), rng.uniform(-5.2, 5.2, 500), rng.uniform(-np.pi, np.pi, 500)])
+    v0, g0 = og.all_with_grad(pos)
+    v1, g1 = e32.terrain(pos)
+    assert np.abs(v0 - v1).max() < 1e-12 and np.abs(g0 - g1).max() / np.abs(g0).max() < 1e-12
+    a = oracle.OracleALM(og)
+    x0 = a.setup(hill_problem)
+    f, g, _ = a.eval(x0)
+    r = e32.run(0, hill_problem, x0)
+    assert abs(f - r["f"]) / abs(f) < 1e-11 and rel(g, r["g"]) < 1e-10
+    # and it is a different grid from the fp64 one (the rounding is visible at 1e-8, far above the tolerances above)
+    assert np.abs(rounded - analytic_cells).max() > 1e-9
+
+
 def test_emu_full_solve_tracks_oracle(emu, oracle, oracle_grid, small_problems):
     """the workgroup program's state machine (ALM / L-BFGS / line search / two-loop) against the oracle"""
     E.lib().emu_set_lanes(256)

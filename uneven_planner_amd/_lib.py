@@ -24,6 +24,14 @@ class OptParams(C.Structure):
                 ("mem_size", C.c_int32), ("past", C.c_int32), ("int_K", C.c_int32)]
 
 
+class FbmParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("hurst", C.c_double), ("lambda_min", C.c_double), ("lambda_max", C.c_double),
+                ("amplitude", C.c_double), ("max_slope_deg", C.c_double), ("n_waves", C.c_int32), ("rough_amp", C.c_double),
+                ("rough_lambda", C.c_double), ("patch_lambda", C.c_double), ("rough_threshold", C.c_double)]
+
+
+FBM_MAX_WAVES = 48
+FBM_TABLE_DOUBLES = 4 * FBM_MAX_WAVES + 12 + 9
 DP = C.POINTER(C.c_double)
 
 
@@ -49,6 +57,11 @@ SYMBOLS = {
     "uph_device_count": (C.c_int, []),
     "uph_version": (C.c_char_p, []),
     "uph_map_create": (C.c_int, [C.POINTER(MapParams), C.c_int, C.POINTER(_VP)]),
+    "uph_map_create_f32": (C.c_int, [C.POINTER(MapParams), C.c_int, C.POINTER(_VP)]),
+    "uph_map_storage_bytes": (C.c_int, [_VP]),
+    "uph_map_fill_fbm": (C.c_int, [_VP, C.POINTER(FbmParams), _I32, _I32]),
+    "uph_fbm_table": (C.c_int, [C.POINTER(FbmParams), DP]),
+    "uph_map_get_window": (C.c_int, [_VP, _I32, _I32, _I32, _I32, DP]),
     "uph_map_destroy": (None, [_VP]),
     "uph_map_dims": (C.c_int, [_VP, C.POINTER(_I32)]),
     "uph_map_set_cells": (C.c_int, [_VP, DP]),

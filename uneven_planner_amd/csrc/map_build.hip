@@ -33,8 +33,9 @@ struct uph_map {
     uph_map_params mp;
     GridDev g;
     size_t ncell = 0;
-    double* d_cells = nullptr;   // AoS ncell x 4 {z, sigma, zbx, zby}  (the array that is all-gathered across GPUs)
-    double* d_planes = nullptr;  // SoA: sigma | zbx | zby | z | c   (5 * ncell)
+    double* d_cells = nullptr;   // ncell x 4 doubles {z, sigma, zbx, zby}: the array every lookup gathers and RCCL all-gathers across GPUs
+    float* d_cells32 = nullptr;  // fp32 storage mode (uph_map_create_f32): ncell x 4 floats instead of d_cells
+    double* d_c = nullptr;       // c_buffer (fp64 storage only)
     char* d_occ = nullptr;       // ncell
     char* d_occ2 = nullptr;      // nx * ny
     double last_build_ms = 0.0, last_query_ms = 0.0;
@@ -253,23 +254,139 @@ __global__ __launch_bounds__(64) void uph_map_build_kernel(GridDev g, CloudDev c
     }
 }
 
-// AoS cells -> SoA planes + c + occupancy (uneven_map.cpp:170-179).  One thread per (x,y) column.
-__global__ void uph_map_commit_kernel(int nx, int ny, int nyaw, const double* __restrict__ cells, double* __restrict__ planes, char* __restrict__ occ,
-                                      char* __restrict__ occ2, double min_cnormal, double max_rho) {
+// cells -> c_buffer + occupancy (uneven_map.cpp:170-179, 385, 390).  One thread per (x,y) column.
+__global__ void uph_map_commit_kernel(int nx, int ny, int nyaw, const double* __restrict__ cells, const float* __restrict__ cells32, double* __restrict__ cbuf,
+                                      char* __restrict__ occ, char* __restrict__ occ2, double min_cnormal, double max_rho) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= nx * ny) return;
-    const size_t ncell = (size_t)nx * ny * nyaw;
     char any = 0;
     for (int w = 0; w < nyaw; w++) {
         const size_t a = (size_t)col * nyaw + w;
-        const double z = cells[a * 4], sg = cells[a * 4 + 1], zx = cells[a * 4 + 2], zy = cells[a * 4 + 3];
+        double sg, zx, zy;
+        if (cells32) { sg = (double)cells32[a * 4 + 1]; zx = (double)cells32[a * 4 + 2]; zy = (double)cells32[a * 4 + 3]; }
+        else { sg = cells[a * 4 + 1]; zx = cells[a * 4 + 2]; zy = cells[a * 4 + 3]; }
         const double c = sqrt(1.0 - zx * zx - zy * zy);
-        planes[a] = sg; planes[ncell + a] = zx; planes[2 * ncell + a] = zy; planes[3 * ncell + a] = z; planes[4 * ncell + a] = c;
+        if (cbuf) cbuf[a] = c;
         const char o = (c < min_cnormal || sg > max_rho) ? 1 : 0;
         occ[a] = o;
         any |= o;
     }
     occ2[col] = any;
+}
+
+// ------------------------------------------------------------------------------------------------ analytic fractal terrain (BASELINE.json configs[4])
+// Height field of the synthetic 1 km^2 scene: a spectral fBm sum of plane waves (amplitude ~ wavelength^H, wavelengths log-spaced
+// between lambda_min and lambda_max, random direction and phase from the seed) plus short-wavelength ripples confined to "rough"
+// patches by a smooth envelope, so that sigma reaches the occupancy / max_sig thresholds somewhere.  No point cloud exists for it:
+// the cell fit below is UnevenMap::constructMap (uneven_map.cpp:329-391, filter :5-43) with the radius search replaced by a fixed
+// body-frame lattice of surface samples inside the robot ellipsoid's footprint.
+struct FbmDev {
+    int nw;
+    double a[UPH_FBM_MAX_WAVES], kx[UPH_FBM_MAX_WAVES], ky[UPH_FBM_MAX_WAVES], ph[UPH_FBM_MAX_WAVES];
+    double rq[4][3];          // ripple waves: kx, ky, phase
+    double ev[3][3];          // envelope waves
+    double rough_amp, rough_thr;
+};
+
+__device__ __forceinline__ double fbmHeight(const FbmDev& f, double x, double y) {
+    double h = 0.0;
+    for (int i = 0; i < f.nw; i++) h += f.a[i] * cos(f.kx[i] * x + f.ky[i] * y + f.ph[i]);
+    double e = 0.0;
+#pragma unroll
+    for (int m = 0; m < 3; m++) e += cos(f.ev[m][0] * x + f.ev[m][1] * y + f.ev[m][2]);
+    e = 0.5 + e * (0.5 / 3.0);
+    double E = (e - f.rough_thr) / (1.0 - f.rough_thr);
+    E = fmin(fmax(E, 0.0), 1.0);
+    if (E > 0.0) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) r += cos(f.rq[j][0] * x + f.rq[j][1] * y + f.rq[j][2]);
+        h += f.rough_amp * E * E * 0.25 * r;
+    }
+    return h;
+}
+
+// lattice of the fit in units of the ellipsoid's x / y semi-axes (all 15 nodes inside the unit disc)
+__constant__ double UPH_FBM_LU[5] = {-0.75, -0.375, 0.0, 0.375, 0.75};
+__constant__ double UPH_FBM_LV[3] = {-0.6, 0.0, 0.6};
+
+// one wave64 per (x,y) column of the slab [x0, x1), lane = yaw bin (+64 per trip)
+template <typename CellT>
+__global__ __launch_bounds__(64) void uph_map_fbm_kernel(GridDev g, FbmDev f, CellT* __restrict__ cells, int x0, int x1, int iter_num, double ell_x, double ell_y) {
+    const int col = blockIdx.x;
+    const int x = x0 + col / g.ny, y = col % g.ny;
+    if (x >= x1) return;
+    const double ccx = (x + 0.5) * g.xy_res + g.origin[0];           // indexToPos, uneven_map.h:419-425
+    const double ccy = (y + 0.5) * g.xy_res + g.origin[1];
+    for (int yaw = threadIdx.x; yaw < g.nyaw; yaw += 64) {
+        const size_t addr = ((size_t)x * g.ny + y) * g.nyaw + yaw;
+        double cz = 0.0, csig = 0.0, czbx = 0.0, czby = 0.0, cc = 1.0;      // fresh RXS2(), c = 1 (uneven_map.cpp:117-119)
+        const double yawc = (yaw + 0.5) * g.yaw_res + g.origin[2];
+        const double cyw = cos(yawc), syw = sin(yawc);
+        for (int iter = 0; iter < iter_num; iter++) {
+            const double zb0 = czbx, zb1 = czby, zb2 = cc;                   // body frame from the current normal (:333-340)
+            double yb0 = zb1 * 0.0 - zb2 * syw, yb1 = zb2 * cyw - zb0 * 0.0, yb2 = zb0 * syw - zb1 * cyw;
+            const double ybn = sqrt(yb0 * yb0 + yb1 * yb1 + yb2 * yb2);
+            yb0 /= ybn; yb1 /= ybn; yb2 /= ybn;
+            const double xb0 = yb1 * zb2 - yb2 * zb1, xb1 = yb2 * zb0 - yb0 * zb2;
+            const double wx = ccx + xb0 * 0.12, wy = ccy + xb1 * 0.12;        // probe point (:341-342)
+            double px[15], py[15], pz[15];
+            double sx = 0, sy = 0, sz = 0;
+#pragma unroll
+            for (int a = 0; a < 5; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const double u = UPH_FBM_LU[a] * ell_x, v = UPH_FBM_LV[b] * ell_y;
+                    const int t = a * 3 + b;
+                    px[t] = wx + u * xb0 + v * yb0;
+                    py[t] = wy + u * xb1 + v * yb1;
+                    pz[t] = fbmHeight(f, px[t], py[t]);
+                    sx += px[t]; sy += py[t]; sz += pz[t];
+                }
+            const double mx = sx / 15.0, my = sy / 15.0, mz = sz / 15.0;
+            double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+#pragma unroll
+            for (int t = 0; t < 15; t++) {
+                const double v0 = px[t] - mx, v1 = py[t] - my, v2 = pz[t] - mz;
+                c00 += v0 * v0; c01 += v0 * v1; c02 += v0 * v2; c11 += v1 * v1; c12 += v1 * v2; c22 += v2 * v2;
+            }
+            const double inv = 1.0 / 15.0;
+            double D[3], V[3][3];
+            jacobiEig3(c00 * inv, c01 * inv, c02 * inv, c11 * inv, c12 * inv, c22 * inv, D, V);
+            int im = 0;                                               // D.minCoeff (:25-26)
+            if (D[1] < D[im]) im = 1;
+            if (D[2] < D[im]) im = 2;
+            double n0 = V[0][im], n1 = V[1][im], n2 = V[2][im];
+            const double nn = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+            n0 /= nn; n1 /= nn; n2 /= nn;
+            if (n2 < 0.0) { n0 = -n0; n1 = -n1; n2 = -n2; }
+            double sig = D[im] / (D[0] + D[1] + D[2]) * 3.0;          // :31
+            if (isnan(sig)) { sig = 1.0; n0 = 1.0; n1 = 0.0; n2 = 0.0; }
+            cz = mz; csig = sig; czbx = n0; czby = n1;
+            cc = sqrt(1.0 - czbx * czbx - czby * czby);
+        }
+        cells[addr * 4 + 0] = (CellT)cz; cells[addr * 4 + 1] = (CellT)csig; cells[addr * 4 + 2] = (CellT)czbx; cells[addr * 4 + 3] = (CellT)czby;
+    }
+}
+
+// storage conversions for the host-facing copies of an fp32 map
+__global__ void uph_cvt_f64_f32(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+__global__ void uph_cvt_f32_f64(const float* __restrict__ src, double* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
+}
+// xy window [x0, x1) x [y0, y1), all yaw bins, as doubles whatever the storage
+__global__ void uph_window_kernel(int ny, int nyaw, const double* __restrict__ cells, const float* __restrict__ cells32, int x0, int y0, int wx, int wy, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)nyaw * 4;
+    if (i >= (size_t)wx * wy * per) return;
+    const size_t colw = i / per, r = i % per;
+    const int ix = x0 + (int)(colw / wy), iy = y0 + (int)(colw % wy);
+    const size_t a = ((size_t)ix * ny + iy) * per + r;
+    out[i] = cells32 ? (double)cells32[a] : cells[a];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -329,8 +446,8 @@ HostCloud cropAndVoxel(const float* xyz, int64_t n) {
 int commitMap(uph_map* m) {
     const GridDev& g = m->g;
     const int ncol = g.nx * g.ny;
-    hipLaunchKernelGGL(uph_map_commit_kernel, dim3((ncol + 255) / 256), dim3(256), 0, 0, g.nx, g.ny, g.nyaw, m->d_cells, m->d_planes, m->d_occ, m->d_occ2,
-                       m->mp.min_cnormal, m->mp.max_rho);
+    hipLaunchKernelGGL(uph_map_commit_kernel, dim3((ncol + 255) / 256), dim3(256), 0, 0, g.nx, g.ny, g.nyaw, m->d_cells, m->d_cells32, m->d_c, m->d_occ,
+                       m->d_occ2, m->mp.min_cnormal, m->mp.max_rho);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     return UPH_OK;
@@ -347,7 +464,9 @@ __global__ void uph_frontend_kernel(GridDev g, const char* __restrict__ occ, con
     const double x = pos[3 * i], y = pos[3 * i + 1], w = pos[3 * i + 2];
     Corners c;
     locate(g, x, y, w, c);
-    sigma[i] = c.inmap ? interpValue(g.sigma, c) : 0.0;
+    double tv[4];
+    terrainValues(g, c, tv);
+    sigma[i] = tv[0];
     const int ix = (int)floor((x - g.origin[0]) * g.xy_inv), iy = (int)floor((y - g.origin[1]) * g.xy_inv), iw = (int)floor((w - g.origin[2]) * g.yaw_inv);
     const bool in = ix >= 0 && iy >= 0 && iw >= 0 && ix <= g.nx - 1 && iy <= g.ny - 1 && iw <= g.nyaw - 1;
     occ_out[i] = in ? (int)occ[((size_t)ix * g.ny + iy) * g.nyaw + iw] : -1;
@@ -362,8 +481,9 @@ __global__ void uph_pose_kernel(GridDev g, const double* __restrict__ pos, int n
     const double x = pos[3 * i], y = pos[3 * i + 1], w = pos[3 * i + 2];
     Corners c;
     locate(g, x, y, w, c);
-    double z = 0.0, zx = 0.0, zy = 0.0;
-    if (c.inmap) { z = interpValue(g.z, c); zx = interpValue(g.zbx, c); zy = interpValue(g.zby, c); }
+    double tv[4];
+    terrainValues(g, c, tv);
+    const double z = tv[3], zx = tv[1], zy = tv[2];
     const double zz = sqrt(1.0 - zx * zx - zy * zy);                 // RXS2::getC
     const double cw = cos(w), sw = sin(w);
     double y0 = zy * 0.0 - zz * sw, y1 = zz * cw - zx * 0.0, y2 = zx * sw - zy * cw;      // zb x xyaw
@@ -377,7 +497,7 @@ __global__ void uph_pose_kernel(GridDev g, const double* __restrict__ pos, int n
 
 extern "C" {
 
-int uph_map_create(const uph_map_params* mp, int device, uph_map** out) {
+static int createMap(const uph_map_params* mp, int device, uph_map** out, bool f32) {
     if (!mp || !out) { setError("uph_map_create: null argument"); return UPH_ERR_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { setError("uph_map_create: no HIP device visible"); return UPH_ERR_NO_DEVICE; }
@@ -396,23 +516,35 @@ int uph_map_create(const uph_map_params* mp, int device, uph_map** out) {
     g.nx = (int)std::ceil(size[0] / g.xy_res); g.ny = (int)std::ceil(size[1] / g.xy_res); g.nyaw = (int)std::ceil(size[2] / g.yaw_res);   // :108-110
     g.gravity = mp->gravity;
     m->ncell = (size_t)g.nx * g.ny * g.nyaw;
-    HIPCHK(hipMalloc((void**)&m->d_cells, m->ncell * 4 * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&m->d_planes, m->ncell * 5 * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&m->d_occ, m->ncell));
-    HIPCHK(hipMalloc((void**)&m->d_occ2, (size_t)g.nx * g.ny));
-    HIPCHK(hipMemset(m->d_cells, 0, m->ncell * 4 * sizeof(double)));                 // map_buffer = RXS2() zeros (:118)
-    g.sigma = m->d_planes; g.zbx = m->d_planes + m->ncell; g.zby = m->d_planes + 2 * m->ncell; g.z = m->d_planes + 3 * m->ncell;
-    g.cells = m->d_cells;
-    int r = commitMap(m);
-    if (r != UPH_OK) { delete m; return r; }
+    g.cells = nullptr; g.cells32 = nullptr;
+    int r = UPH_OK;
+    auto alloc = [&](void** p, size_t bytes) { if (r == UPH_OK && hipMalloc(p, bytes) != hipSuccess) { setError("uph_map_create: hipMalloc of the grid failed"); r = UPH_ERR_HIP; } };
+    if (f32) {
+        alloc((void**)&m->d_cells32, m->ncell * 4 * sizeof(float));
+        if (r == UPH_OK && hipMemset(m->d_cells32, 0, m->ncell * 4 * sizeof(float)) != hipSuccess) r = UPH_ERR_HIP;
+        g.cells32 = m->d_cells32;
+    } else {
+        alloc((void**)&m->d_cells, m->ncell * 4 * sizeof(double));
+        alloc((void**)&m->d_c, m->ncell * sizeof(double));
+        if (r == UPH_OK && hipMemset(m->d_cells, 0, m->ncell * 4 * sizeof(double)) != hipSuccess) r = UPH_ERR_HIP;   // map_buffer = RXS2() zeros (:118)
+        g.cells = m->d_cells;
+    }
+    alloc((void**)&m->d_occ, m->ncell);
+    alloc((void**)&m->d_occ2, (size_t)g.nx * g.ny);
+    if (r == UPH_OK) r = commitMap(m);
+    if (r != UPH_OK) { uph_map_destroy(m); return r; }
     *out = m;
     return UPH_OK;
 }
 
+int uph_map_create(const uph_map_params* mp, int device, uph_map** out) { return createMap(mp, device, out, false); }
+int uph_map_create_f32(const uph_map_params* mp, int device, uph_map** out) { return createMap(mp, device, out, true); }
+int uph_map_storage_bytes(const uph_map* m) { return !m ? UPH_ERR_INVALID : (m->d_cells32 ? 4 : 8); }
+
 void uph_map_destroy(uph_map* m) {
     if (!m) return;
     hipSetDevice(m->device);
-    hipFree(m->d_cells); hipFree(m->d_planes); hipFree(m->d_occ); hipFree(m->d_occ2);
+    hipFree(m->d_cells); hipFree(m->d_cells32); hipFree(m->d_c); hipFree(m->d_occ); hipFree(m->d_occ2);
     delete m;
 }
 
@@ -422,49 +554,168 @@ int uph_map_dims(const uph_map* m, int32_t dims3[3]) {
     return UPH_OK;
 }
 
+// host <-> fp32 storage in chunks through a bounded fp64 staging buffer
+static int copyCellsF32(uph_map* m, const double* from_host, double* to_host) {
+    const size_t total = m->ncell * 4, chunk = std::min<size_t>(total, (size_t)64 << 20);
+    UphDevTmp st;
+    HIPCHK(hipMalloc(&st.p, chunk * sizeof(double)));
+    for (size_t o = 0; o < total; o += chunk) {
+        const size_t n = std::min(chunk, total - o);
+        if (from_host) {
+            HIPCHK(hipMemcpy(st.p, from_host + o, n * sizeof(double), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(uph_cvt_f64_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, st.as<double>(), m->d_cells32 + o, n);
+        } else {
+            hipLaunchKernelGGL(uph_cvt_f32_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, m->d_cells32 + o, st.as<double>(), n);
+            HIPCHK(hipMemcpy(to_host + o, st.p, n * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+    }
+    return UPH_OK;
+}
+
 int uph_map_set_cells(uph_map* m, const double* rxs2) {
     if (!m || !rxs2) { setError("uph_map_set_cells: null argument"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
-    HIPCHK(hipMemcpy(m->d_cells, rxs2, m->ncell * 4 * sizeof(double), hipMemcpyHostToDevice));
+    if (m->d_cells32) { const int r = copyCellsF32(m, rxs2, nullptr); if (r != UPH_OK) return r; }
+    else HIPCHK(hipMemcpy(m->d_cells, rxs2, m->ncell * 4 * sizeof(double), hipMemcpyHostToDevice));
     return commitMap(m);
 }
 
 int uph_map_get_cells(uph_map* m, double* rxs2, double* c, char* occ, char* occ_r2) {
     if (!m) return UPH_ERR_INVALID;
     HIPCHK(hipSetDevice(m->device));
-    if (rxs2) HIPCHK(hipMemcpy(rxs2, m->d_cells, m->ncell * 4 * sizeof(double), hipMemcpyDeviceToHost));
-    if (c) HIPCHK(hipMemcpy(c, m->d_planes + 4 * m->ncell, m->ncell * sizeof(double), hipMemcpyDeviceToHost));
+    if (c && !m->d_c) { setError("uph_map_get_cells: c_buffer is not kept in fp32 storage mode"); return UPH_ERR_INVALID; }
+    if (rxs2) {
+        if (m->d_cells32) { const int r = copyCellsF32(m, nullptr, rxs2); if (r != UPH_OK) return r; }
+        else HIPCHK(hipMemcpy(rxs2, m->d_cells, m->ncell * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (c) HIPCHK(hipMemcpy(c, m->d_c, m->ncell * sizeof(double), hipMemcpyDeviceToHost));
     if (occ) HIPCHK(hipMemcpy(occ, m->d_occ, m->ncell, hipMemcpyDeviceToHost));
     if (occ_r2) HIPCHK(hipMemcpy(occ_r2, m->d_occ2, (size_t)m->g.nx * m->g.ny, hipMemcpyDeviceToHost));
     return UPH_OK;
 }
 
+int uph_map_get_window(uph_map* m, int32_t x0, int32_t x1, int32_t y0, int32_t y1, double* rxs2) {
+    if (!m || !rxs2 || x0 < 0 || y0 < 0 || x1 > m->g.nx || y1 > m->g.ny || x0 >= x1 || y0 >= y1) { setError("uph_map_get_window: bad arguments"); return UPH_ERR_INVALID; }
+    HIPCHK(hipSetDevice(m->device));
+    const size_t n = (size_t)(x1 - x0) * (y1 - y0) * m->g.nyaw * 4;
+    UphDevTmp t;
+    HIPCHK(hipMalloc(&t.p, n * sizeof(double)));
+    hipLaunchKernelGGL(uph_window_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, m->g.ny, m->g.nyaw, m->d_cells, m->d_cells32, x0, y0, x1 - x0, y1 - y0, t.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(rxs2, t.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return UPH_OK;
+}
+
+static size_t cellBytes(const uph_map* m) { return 4 * (m->d_cells32 ? sizeof(float) : sizeof(double)); }
+static char* cellBase(uph_map* m) { return m->d_cells32 ? (char*)m->d_cells32 : (char*)m->d_cells; }
+
 int uph_map_cells_device(uph_map* m, void** dptr, int64_t* nbytes) {
     if (!m || !dptr || !nbytes) return UPH_ERR_INVALID;
-    *dptr = m->d_cells;
-    *nbytes = (int64_t)(m->ncell * 4 * sizeof(double));
+    *dptr = cellBase(m);
+    *nbytes = (int64_t)(m->ncell * cellBytes(m));
     return UPH_OK;
 }
 
 // device-to-device slab traffic for the sharded build: export this rank's x-slab into a caller buffer (e.g. a torch tensor
-// that RCCL all-gathers), import the gathered full cell array
+// that RCCL all-gathers), import the gathered full cell array.  Element type = the map's storage (double, or float in fp32 mode)
 int uph_map_export_slab_dev(uph_map* m, int32_t x0, int32_t x1, void* dst_dev) {
     if (!m || !dst_dev || x0 < 0 || x1 > m->g.nx || x0 >= x1) { setError("uph_map_export_slab_dev: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
-    const size_t per_x = (size_t)m->g.ny * m->g.nyaw * 4 * sizeof(double);
-    HIPCHK(hipMemcpy(dst_dev, (const char*)m->d_cells + (size_t)x0 * per_x, (size_t)(x1 - x0) * per_x, hipMemcpyDeviceToDevice));
+    const size_t per_x = (size_t)m->g.ny * m->g.nyaw * cellBytes(m);
+    HIPCHK(hipMemcpy(dst_dev, cellBase(m) + (size_t)x0 * per_x, (size_t)(x1 - x0) * per_x, hipMemcpyDeviceToDevice));
     return UPH_OK;
 }
 int uph_map_import_cells_dev(uph_map* m, const void* src_dev) {
     if (!m || !src_dev) { setError("uph_map_import_cells_dev: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
-    HIPCHK(hipMemcpy(m->d_cells, src_dev, m->ncell * 4 * sizeof(double), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(cellBase(m), src_dev, m->ncell * cellBytes(m), hipMemcpyDeviceToDevice));
     return commitMap(m);
 }
 
 int uph_map_commit(uph_map* m) {
     if (!m) return UPH_ERR_INVALID;
     HIPCHK(hipSetDevice(m->device));
+    return commitMap(m);
+}
+
+// wave table of the analytic terrain from the seed (splitmix64 stream, three uniforms per wave: wavelength jitter, direction, phase)
+static void buildFbm(const uph_fbm_params& fp, FbmDev& f) {
+    uint64_t st = fp.seed;
+    auto next = [&]() {
+        st += 0x9E3779B97F4A7C15ull;
+        uint64_t z = st;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    };
+    const double TWO_PI = 6.28318530717958647692;
+    f.nw = fp.n_waves;
+    double sa = 0.0, sk = 0.0;
+    for (int i = 0; i < f.nw; i++) {
+        const double u1 = next(), u2 = next(), u3 = next();
+        const double lam = fp.lambda_min * std::pow(fp.lambda_max / fp.lambda_min, ((double)i + u1) / (double)f.nw);
+        const double k = TWO_PI / lam, th = TWO_PI * u2;
+        f.kx[i] = k * std::cos(th); f.ky[i] = k * std::sin(th); f.ph[i] = TWO_PI * u3;
+        f.a[i] = std::pow(lam, fp.hurst);
+        sa += f.a[i]; sk += f.a[i] * k;
+    }
+    const double PI = 3.14159265358979323846;
+    const double c = std::min(fp.amplitude / sa, std::tan(fp.max_slope_deg * PI / 180.0) / sk);    // both bounds hold in the worst case (all waves in phase)
+    for (int i = 0; i < f.nw; i++) f.a[i] *= c;
+    for (int i = f.nw; i < UPH_FBM_MAX_WAVES; i++) { f.a[i] = 0.0; f.kx[i] = 0.0; f.ky[i] = 0.0; f.ph[i] = 0.0; }
+    for (int j = 0; j < 4; j++) {
+        const double u1 = next(), u2 = next(), u3 = next();
+        const double k = TWO_PI / (fp.rough_lambda * (0.8 + 0.4 * u1)), th = TWO_PI * u2;
+        f.rq[j][0] = k * std::cos(th); f.rq[j][1] = k * std::sin(th); f.rq[j][2] = TWO_PI * u3;
+    }
+    for (int j = 0; j < 3; j++) {
+        const double u1 = next(), u2 = next(), u3 = next();
+        const double k = TWO_PI / (fp.patch_lambda * (1.0 + 2.0 * u1)), th = TWO_PI * u2;
+        f.ev[j][0] = k * std::cos(th); f.ev[j][1] = k * std::sin(th); f.ev[j][2] = TWO_PI * u3;
+    }
+    f.rough_amp = fp.rough_amp; f.rough_thr = fp.rough_threshold;
+}
+static bool checkFbm(const uph_fbm_params* fp) {
+    return fp && fp->n_waves >= 1 && fp->n_waves <= UPH_FBM_MAX_WAVES && fp->lambda_min > 0 && fp->lambda_max >= fp->lambda_min && fp->rough_lambda > 0 &&
+           fp->patch_lambda > 0 && fp->rough_threshold < 1.0 && fp->max_slope_deg > 0 && fp->max_slope_deg < 90 && fp->amplitude > 0;
+}
+
+int uph_fbm_table(const uph_fbm_params* fp, double* table) {
+    if (!checkFbm(fp) || !table) { setError("uph_fbm_table: bad arguments"); return UPH_ERR_INVALID; }
+    FbmDev f;
+    buildFbm(*fp, f);
+    double* t = table;
+    for (int i = 0; i < UPH_FBM_MAX_WAVES; i++) { *t++ = f.a[i]; *t++ = f.kx[i]; *t++ = f.ky[i]; *t++ = f.ph[i]; }
+    for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) *t++ = f.rq[j][k];
+    for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) *t++ = f.ev[j][k];
+    return UPH_OK;
+}
+
+int uph_map_fill_fbm(uph_map* m, const uph_fbm_params* fp, int32_t x0, int32_t x1) {
+    if (!m || !checkFbm(fp)) { setError("uph_map_fill_fbm: bad arguments"); return UPH_ERR_INVALID; }
+    if (x1 <= 0) x1 = m->g.nx;
+    if (x0 < 0 || x1 > m->g.nx || x0 >= x1) { setError("uph_map_fill_fbm: bad slab"); return UPH_ERR_INVALID; }
+    HIPCHK(hipSetDevice(m->device));
+    FbmDev f;
+    buildFbm(*fp, f);
+    UphEventTmp e0, e1;
+    HIPCHK(hipEventCreate((hipEvent_t*)&e0.e)); HIPCHK(hipEventCreate((hipEvent_t*)&e1.e));
+    const size_t ncol = (size_t)(x1 - x0) * m->g.ny;
+    if (ncol > (size_t)INT32_MAX) { setError("uph_map_fill_fbm: slab has more than 2^31 columns"); return UPH_ERR_LIMIT; }
+    HIPCHK(hipEventRecord((hipEvent_t)e0.e, 0));
+    if (m->d_cells32) hipLaunchKernelGGL(uph_map_fbm_kernel<float>, dim3((unsigned)ncol), dim3(64), 0, 0, m->g, f, m->d_cells32, (int)x0, (int)x1, (int)m->mp.iter_num, m->mp.ellipsoid_x, m->mp.ellipsoid_y);
+    else hipLaunchKernelGGL(uph_map_fbm_kernel<double>, dim3((unsigned)ncol), dim3(64), 0, 0, m->g, f, m->d_cells, (int)x0, (int)x1, (int)m->mp.iter_num, m->mp.ellipsoid_x, m->mp.ellipsoid_y);
+    HIPCHK(hipEventRecord((hipEvent_t)e1.e, 0));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)e0.e, (hipEvent_t)e1.e));
+    m->last_build_ms = ms;
+    m->last_cell_iters = (int64_t)(x1 - x0) * m->g.ny * m->g.nyaw * m->mp.iter_num;
+    m->last_cloud = 0;
     return commitMap(m);
 }
 
@@ -477,6 +728,7 @@ int uph_map_build_stats(uph_map* m, double* kernel_ms, int64_t* cell_iters, int6
 }
 
 int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x1) {
+    if (m && m->d_cells32) { setError("uph_map_build: the plane fit writes fp64 cells; create the map with uph_map_create"); return UPH_ERR_INVALID; }
     if (!m || !xyz || n <= 0) { setError("uph_map_build: bad arguments"); return UPH_ERR_INVALID; }
     const GridDev& g = m->g;
     if (x0 < 0 || x1 > g.nx || x0 >= x1) { setError("uph_map_build: bad x-slab"); return UPH_ERR_INVALID; }

@@ -34,10 +34,6 @@
 namespace uph {
 
 // scatter batch widths (LDS reads in flight per lane): xy blocks hold K + 1 = 17 records, yaw candidates ~40
-// terrain gathers of the penalty kernel: 1 = array-of-cells form (16 x 16-byte loads per sample), 0 = three field planes (24 x 8-byte)
-#ifndef UPH_TERRAIN_CELLS
-#define UPH_TERRAIN_CELLS 1
-#endif
 #ifndef UPH_SC_XB
 #define UPH_SC_XB 17
 #endif
@@ -277,11 +273,7 @@ struct Solver {
     // gradients are never formed individually (sampleEval folds them into four scalar coefficients)
     UPH_HD void terrainValuesOnly(Kin& S_) const {
         double sg;
-#if UPH_TERRAIN_CELLS
-        terrainBaseCells(grid, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
-#else
         terrainBase(grid, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
-#endif
         const double zx = S_.zx, zy = S_.zy;
         const double cc = sqrt(1.0 - zx * zx - zy * zy);                 // uneven_map.h:327-348
         const double inv_c = 1.0 / cc;

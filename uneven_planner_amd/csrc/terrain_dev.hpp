@@ -1,8 +1,7 @@
 // Device terrain lookup: trilinear SE(2) interpolation of (sigma, zb) with analytic gradients and the derived
 // attitude terms.  Twin of UnevenMap::getTerrainWithGradI / getAllWithGrad / getTerrain / getTerrainVariables
 // (uneven_map/include/uneven_map/uneven_map.h:154-201, 221-256, 258-315, 318-377), index helpers :398-454.
-// Reads the SoA planes of GridDev: for each (x,y) corner the two yaw neighbours are adjacent in memory (yaw fastest),
-// so a corner pair is one 16-byte access unless the yaw index wraps (64-bin period, uneven_map.h:403-406).
+// Reads the array of cells of GridDev (the build output itself): {z, sigma, zb.x, zb.y} per cell, yaw fastest.
 #pragma once
 #include "uph_common.hpp"
 
@@ -60,57 +59,104 @@ UPH_HD void locate(const GridDev& g, double x, double y, double yaw, Corners& c)
     c.a[1][1] = ((int64_t)x1 * g.ny + y1) * g.nyaw;
 }
 
-// trilinear value and gradient of one field plane, operation order of uneven_map.h:297-311
-UPH_HD void interpField(const double* __restrict__ f, const Corners& c, double& val, double& gx, double& gy, double& gw,
-                        double xy_inv, double yaw_inv) {
-    double v[2][2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            v[a][b][0] = f[c.a[a][b] + c.w0];
-            v[a][b][1] = f[c.a[a][b] + c.w1];
-        }
-    const double dx = c.dx, dy = c.dy, dw = c.dyaw;
-    double v00 = v[0][0][0] * (1 - dx) + v[1][0][0] * dx;
-    double v01 = v[0][0][1] * (1 - dx) + v[1][0][1] * dx;
-    double v10 = v[0][1][0] * (1 - dx) + v[1][1][0] * dx;
-    double v11 = v[0][1][1] * (1 - dx) + v[1][1][1] * dx;
-    double v0 = v00 * (1 - dy) + v10 * dy;
-    double v1 = v01 * (1 - dy) + v11 * dy;
-    val = v0 * (1 - dw) + v1 * dw;
-    gw = (v1 - v0) * yaw_inv;
-    gy = ((v10 - v00) * (1 - dw) + (v11 - v01) * dw) * xy_inv;
-    double g0 = (1 - dw) * (1 - dy) * (v[1][0][0] - v[0][0][0]);
-    g0 += (1 - dw) * dy * (v[1][1][0] - v[0][1][0]);
-    g0 += dw * (1 - dy) * (v[1][0][1] - v[0][0][1]);
-    g0 += dw * dy * (v[1][1][1] - v[0][1][1]);
-    gx = g0 * xy_inv;
+// One cell of the grid: {z, sigma, zb.x, zb.y} in the reference's RXS2 order (uneven_map.h:36-64, 427-435), stored either as four
+// doubles (32 bytes, two 16-byte loads; bit-faithful to the reference's map_buffer) or -- GridDev::cells32, BASELINE.json configs[4] --
+// as four floats (16 bytes, one load) widened to double on load: the arithmetic is fp64 either way.
+template <bool F32>
+UPH_HD void loadCell(const GridDev& g, int64_t idx, double f[4]) {      // f = {sigma, zb.x, zb.y, z}
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef double dbl2_t __attribute__((ext_vector_type(2)));
+    typedef float flt4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) dbl2_t* cellp;
+    typedef const __attribute__((address_space(1))) flt4_t* cellp32;
+#else
+    struct dbl2_t { double x, y; };
+    struct flt4_t { float x, y, z, w; };
+    typedef const dbl2_t* cellp;
+    typedef const flt4_t* cellp32;
+#endif
+    if (F32) {
+        const flt4_t v = ((cellp32)g.cells32)[idx];
+        f[3] = (double)v.x; f[0] = (double)v.y; f[1] = (double)v.z; f[2] = (double)v.w;
+    } else {
+        const cellp p = (cellp)(g.cells + 4 * idx);
+        const dbl2_t lo = p[0], hi = p[1];                  // (z, sigma), (zb.x, zb.y)
+        f[3] = lo.x; f[0] = lo.y; f[1] = hi.x; f[2] = hi.y;
+    }
 }
 
-UPH_HD double interpValue(const double* __restrict__ f, const Corners& c) {       // uneven_map.h:192-198
-    double v00 = f[c.a[0][0] + c.w0] * (1 - c.dx) + f[c.a[1][0] + c.w0] * c.dx;
-    double v01 = f[c.a[0][0] + c.w1] * (1 - c.dx) + f[c.a[1][0] + c.w1] * c.dx;
-    double v10 = f[c.a[0][1] + c.w0] * (1 - c.dx) + f[c.a[1][1] + c.w0] * c.dx;
-    double v11 = f[c.a[0][1] + c.w1] * (1 - c.dx) + f[c.a[1][1] + c.w1] * c.dx;
-    double v0 = v00 * (1 - c.dy) + v10 * c.dy;
-    double v1 = v01 * (1 - c.dy) + v11 * c.dy;
-    return v0 * (1 - c.dyaw) + v1 * c.dyaw;
+// Trilinear values val[k] (k = 0 sigma, 1 zb.x, 2 zb.y, 3 z when WITH_Z) and, when GRAD, the gradients grd[k][x, y, yaw] of the first
+// three at a located point: the operations and their order of uneven_map.h:297-311 (values alone: :192-198, the same expressions).
+// One yaw slice at a time -- the bilinear values and the x / y partial sums of a slice need only that slice's four cells, the two
+// slices meet in the last lerp -- so at most four cells are live at once (eight corners = 16 x 16-byte loads in the fp64 form, 8 in fp32).
+template <bool F32, bool GRAD, bool WITH_Z>
+UPH_HD void interpCells(const GridDev& g, const Corners& c, double val[4], double grd[3][3]) {
+    constexpr int NF = WITH_Z ? 4 : 3;
+    const double dx = c.dx, dy = c.dy, dw = c.dyaw;
+    double v0[NF], v1[NF], gy0[3], gy1[3], gx[3];
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        const int wi = w == 0 ? c.w0 : c.w1;
+        double f[2][2][4];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) loadCell<F32>(g, c.a[a][b] + wi, f[a][b]);
+#pragma unroll
+        for (int k = 0; k < NF; k++) {
+            const double vy0 = f[0][0][k] * (1 - dx) + f[1][0][k] * dx;       // v00 / v01 of uneven_map.h:297-300
+            const double vy1 = f[0][1][k] * (1 - dx) + f[1][1][k] * dx;       // v10 / v11
+            const double vv = vy0 * (1 - dy) + vy1 * dy;
+            if (w == 0) v0[k] = vv; else v1[k] = vv;
+            if (GRAD && k < 3) {
+                const double gxa = f[1][0][k] - f[0][0][k], gxb = f[1][1][k] - f[0][1][k];
+                if (w == 0) { gy0[k] = vy1 - vy0; gx[k] = (1 - dw) * (1 - dy) * gxa; gx[k] += (1 - dw) * dy * gxb; }       // :305-308, same summation order
+                else { gy1[k] = vy1 - vy0; gx[k] += dw * (1 - dy) * gxa; gx[k] += dw * dy * gxb; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NF; k++) {
+        val[k] = v0[k] * (1 - dw) + v1[k] * dw;
+        if (GRAD && k < 3) {
+            grd[k][2] = (v1[k] - v0[k]) * g.yaw_inv;
+            grd[k][1] = (gy0[k] * (1 - dw) + gy1[k] * dw) * g.xy_inv;
+            grd[k][0] = gx[k] * g.xy_inv;
+        }
+    }
+}
+
+// Base quantities for the fused penalty kernel: interpolated (sigma, zb.x, zb.y) and their gradients w.r.t. (x, y, yaw).
+UPH_HD void terrainBase(const GridDev& g, double x, double y, double yaw, double& sg, double& zx, double& zy, double gs[3], double gzx[3], double gzy[3]) {
+    Corners c;
+    locate(g, x, y, yaw, c);
+    sg = zx = zy = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { gs[k] = 0.0; gzx[k] = 0.0; gzy[k] = 0.0; }
+    if (!c.inmap) return;                                   // out of map: zeros (uneven_map.h:260-265)
+    double val[4], grd[3][3];
+    if (g.cells32) interpCells<true, true, false>(g, c, val, grd);
+    else interpCells<false, true, false>(g, c, val, grd);
+    sg = val[0]; zx = val[1]; zy = val[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { gs[k] = grd[0][k]; gzx[k] = grd[1][k]; gzy[k] = grd[2][k]; }
+}
+
+// value-only lookup (uneven_map.h:154-201): val = {sigma, zb.x, zb.y, z}, zeros outside the map
+UPH_HD void terrainValues(const GridDev& g, const Corners& c, double val[4]) {
+    val[0] = val[1] = val[2] = val[3] = 0.0;
+    if (!c.inmap) return;
+    double grd[3][3];
+    if (g.cells32) interpCells<true, false, true>(g, c, val, grd);
+    else interpCells<false, false, true>(g, c, val, grd);
 }
 
 // values / gradient rows: 0 invCosVphix, 1 sinPhix, 2 invCosVphiy, 3 sinPhiy, 4 cosXi, 5 invCosXi, 6 sigma
 // (cyaw, syaw) = cos/sin of the WRAPPED yaw (uneven_map.h:329-330)
 UPH_HD void terrainAllWithGrad(const GridDev& g, double x, double y, double yaw, double cyaw, double syaw,
                                double values[7], double grads[7][3]) {
-    Corners c;
-    locate(g, x, y, yaw, c);
-    double sg = 0, zx = 0, zy = 0;
-    double gs[3] = {0, 0, 0}, gzx[3] = {0, 0, 0}, gzy[3] = {0, 0, 0};
-    if (c.inmap) {
-        interpField(g.sigma, c, sg, gs[0], gs[1], gs[2], g.xy_inv, g.yaw_inv);
-        interpField(g.zbx, c, zx, gzx[0], gzx[1], gzx[2], g.xy_inv, g.yaw_inv);
-        interpField(g.zby, c, zy, gzy[0], gzy[1], gzy[2], g.xy_inv, g.yaw_inv);
-    }
+    double sg, zx, zy, gs[3], gzx[3], gzy[3];
+    terrainBase(g, x, y, yaw, sg, zx, zy, gs, gzx, gzy);
     double cc = sqrt(1.0 - zx * zx - zy * zy);                         // RXS2::getC :46
     double gc[3];
 #pragma unroll
@@ -148,95 +194,13 @@ UPH_HD void terrainAllWithGrad(const GridDev& g, double x, double y, double yaw,
     }
 }
 
-// Base quantities for the fused penalty kernel: interpolated (sigma, zb.x, zb.y) and their gradients w.r.t. (x, y, yaw).
-UPH_HD void terrainBase(const GridDev& g, double x, double y, double yaw, double& sg, double& zx, double& zy, double gs[3], double gzx[3], double gzy[3]) {
-    Corners c;
-    locate(g, x, y, yaw, c);
-    sg = zx = zy = 0.0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { gs[k] = 0.0; gzx[k] = 0.0; gzy[k] = 0.0; }
-    if (!c.inmap) return;                                   // out of map: zeros (uneven_map.h:260-265)
-    // one field plane at a time (8 gathers each): issuing all 24 at once was measured slower -- the 48 extra live registers
-    // spill in the register-capped build
-    const double xi = g.xy_inv, wi = g.yaw_inv;
-    double val[3], grd[3][3];
-    interpField(g.sigma, c, val[0], grd[0][0], grd[0][1], grd[0][2], xi, wi);
-    interpField(g.zbx, c, val[1], grd[1][0], grd[1][1], grd[1][2], xi, wi);
-    interpField(g.zby, c, val[2], grd[2][0], grd[2][1], grd[2][2], xi, wi);
-    sg = val[0]; zx = val[1]; zy = val[2];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { gs[k] = grd[0][k]; gzx[k] = grd[1][k]; gzy[k] = grd[2][k]; }
-}
-
-// The same base quantities from the array-of-cells form of the grid (GridDev::cells: {z, sigma, zb.x, zb.y} per cell, the reference's
-// own RXS2 order, uneven_map.h:36-64, 427-435): a cell is 32 bytes, so one corner is two 16-byte loads and the eight corners of a
-// sample are 16 loads on 8 addresses (24 8-byte loads on 24 addresses in the three-plane form).  One yaw slice at a time: the
-// bilinear values and the x / y partial sums of a slice need only that slice's four cells; the two slices meet in the last lerp.
-// Same operations and order as interpField (uneven_map.h:297-311).
-UPH_HD void terrainBaseCells(const GridDev& g, double x, double y, double yaw, double& sg, double& zx, double& zy, double gs[3], double gzx[3], double gzy[3]) {
-    Corners c;
-    locate(g, x, y, yaw, c);
-    sg = zx = zy = 0.0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { gs[k] = 0.0; gzx[k] = 0.0; gzy[k] = 0.0; }
-    if (!c.inmap) return;                                   // out of map: zeros (uneven_map.h:260-265)
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef double dbl2_t __attribute__((ext_vector_type(2)));
-    typedef const __attribute__((address_space(1))) dbl2_t* cellp;
-#else
-    struct dbl2_t { double x, y; };
-    typedef const dbl2_t* cellp;
-#endif
-    const double dx = c.dx, dy = c.dy, dw = c.dyaw;
-    double v0[3], v1[3], gy0[3], gy1[3], gx0[3], gx1[3];      // per yaw slice: bilinear value, (v1x - v0x) blends for d/dy and d/dx
-#pragma unroll
-    for (int w = 0; w < 2; w++) {
-        const int wi = w == 0 ? c.w0 : c.w1;
-        double f[2][2][3];                                  // [a][b][sigma, zb.x, zb.y]
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                const cellp p = (cellp)(g.cells + 4 * (c.a[a][b] + wi));
-                const dbl2_t lo = p[0], hi = p[1];          // (z, sigma), (zb.x, zb.y)
-                f[a][b][0] = lo.y; f[a][b][1] = hi.x; f[a][b][2] = hi.y;
-            }
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const double vy0 = f[0][0][k] * (1 - dx) + f[1][0][k] * dx;       // v00 / v01 of uneven_map.h:297-300
-            const double vy1 = f[0][1][k] * (1 - dx) + f[1][1][k] * dx;       // v10 / v11
-            const double vv = vy0 * (1 - dy) + vy1 * dy;
-            const double gyv = vy1 - vy0;
-            const double gxa = f[1][0][k] - f[0][0][k], gxb = f[1][1][k] - f[0][1][k];
-            if (w == 0) { v0[k] = vv; gy0[k] = gyv; gx0[k] = (1 - dw) * (1 - dy) * gxa; gx0[k] += (1 - dw) * dy * gxb; }
-            else { v1[k] = vv; gy1[k] = gyv; gx1[k] = dw * (1 - dy) * gxa; gx1[k] += dw * dy * gxb; }
-        }
-    }
-    const double xi = g.xy_inv, wi_ = g.yaw_inv;
-    double val[3], grd[3][3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        val[k] = v0[k] * (1 - dw) + v1[k] * dw;
-        grd[k][2] = (v1[k] - v0[k]) * wi_;
-        grd[k][1] = (gy0[k] * (1 - dw) + gy1[k] * dw) * xi;
-        grd[k][0] = (gx0[k] + gx1[k]) * xi;
-    }
-    sg = val[0]; zx = val[1]; zy = val[2];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { gs[k] = grd[0][k]; gzx[k] = grd[1][k]; gzy[k] = grd[2][k]; }
-}
-
 // value-only variant: getTerrain + getTerrainVariables (uneven_map.h:154-201, 221-256).  zout = interpolated z
 UPH_HD void terrainVariables(const GridDev& g, double x, double y, double yaw, double cyaw, double syaw, double values[7], double* zout) {
     Corners c;
     locate(g, x, y, yaw, c);
-    double sg = 0, zx = 0, zy = 0, zz = 0;
-    if (c.inmap) {
-        sg = interpValue(g.sigma, c);
-        zx = interpValue(g.zbx, c);
-        zy = interpValue(g.zby, c);
-        if (zout) zz = interpValue(g.z, c);
-    }
+    double val[4];
+    terrainValues(g, c, val);
+    const double sg = val[0], zx = val[1], zy = val[2], zz = val[3];
     double cc = sqrt(1.0 - zx * zx - zy * zy);
     double inv_c = 1.0 / cc;
     double t = cyaw * zx + syaw * zy;

@@ -71,11 +71,8 @@ struct GridDev {
     double lo[3], hi[3];          // minb + 1e-4, maxb - 1e-4 (isInMap), formed once on the host so that they stay scalar operands
     double half_xy, half_yaw;     // 0.5 * resolution
     double gravity;
-    const double* sigma;
-    const double* zbx;
-    const double* zby;
-    const double* z;
-    const double* cells;          // array-of-cells form {z, sigma, zb.x, zb.y} (the build output, uneven_map.h:36-64 order): what the penalty kernel gathers
+    const double* cells;          // array of cells {z, sigma, zb.x, zb.y} (the build output, uneven_map.h:36-64 order): what every lookup gathers
+    const float* cells32;         // non-null: the same cells stored as four floats (16 bytes); cells is null then (BASELINE.json configs[4])
 };
 
 // Optimiser parameters (alm_traj_opt.h:29-53) + L-BFGS defaults the reference does not override (lbfgs.hpp:76-128)

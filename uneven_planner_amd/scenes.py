@@ -37,27 +37,6 @@ def make_hill_cloud(seed=HILL_SEED, n_side=316, half=6.0, height=hill_height):
     return np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1).astype(np.float32)
 
 
-def fbm_height(seed=7, octaves=6, amplitude=1.5, base_wavelength=40.0, hurst=0.8):
-    """Band-limited spectral fBm heightfield (config 5's synthetic terrain, scaled to a stated amplitude)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    comps = []
-    for o in range(octaves):
-        lam = base_wavelength / (2.0 ** o)
-        amp = amplitude * (2.0 ** (-hurst * o))
-        for _ in range(4):
-            th = rng.random() * 2 * math.pi
-            ph = rng.random() * 2 * math.pi
-            comps.append((amp / 2.0, 2 * math.pi / lam * math.cos(th), 2 * math.pi / lam * math.sin(th), ph))
-
-    def h(x, y):
-        z = np.zeros_like(np.asarray(x, dtype=np.float64))
-        for a, kx, ky, ph in comps:
-            z = z + a * np.sin(kx * x + ky * y + ph)
-        return z + 2.0 * amplitude
-
-    return h
-
-
 def grid_dims(size_x=10.0, size_y=10.0, xy_res=0.05, yaw_res=0.1):
     """uneven_map.cpp:96-110."""
     span = 2.0 * math.pi + 5e-2
@@ -106,6 +85,43 @@ def random_problems(n, seed0=1000, half=4.5, dmin=3.0, dmax=10.0, occ_r2=None, g
                 if not ok:
                     continue
             out.append(make_problem(s, g, **mk))
+            break
+    return out
+
+
+def batch_share(total, rank, world):
+    """strong-scaling split of ONE batch over the ranks (configs[4]): rank r solves problems [lo, lo + count) of the batch"""
+    per = -(-int(total) // int(world))
+    lo = min(rank * per, total)
+    return lo, min(per, total - lo)
+
+
+def local_problems(n, seed0=5000, half=495.0, dmin=4.0, dmax=14.0, occ_r2=None, grid=None, max_pieces=64, **mk):
+    """SURVEY.md 8c row 5 (BASELINE.json configs[4]) protocol: one PCG64 stream per problem (seed0+i): start ~ U([-half,half]^2), goal at
+    distance U[dmin,dmax] in a uniform direction, both yaws ~ U(-pi,pi); accepted when both cells are free, the goal is inside the
+    square and the resampled path has at most max_pieces position pieces (UPH_MAX_PIECE_XY)."""
+    out = []
+    for i in range(n):
+        rng = np.random.Generator(np.random.PCG64(seed0 + i))
+        while True:
+            s = np.array([rng.uniform(-half, half), rng.uniform(-half, half), rng.uniform(-math.pi, math.pi)])
+            d, th = rng.uniform(dmin, dmax), rng.uniform(-math.pi, math.pi)
+            g = np.array([s[0] + d * math.cos(th), s[1] + d * math.sin(th), rng.uniform(-math.pi, math.pi)])
+            if abs(g[0]) > half or abs(g[1]) > half:
+                continue
+            if occ_r2 is not None and grid is not None:
+                nx, ny, res, ox, oy = grid
+                ok = True
+                for p in (s, g):
+                    ix, iy = int(math.floor((p[0] - ox) / res)), int(math.floor((p[1] - oy) / res))
+                    if ix < 0 or iy < 0 or ix >= nx or iy >= ny or occ_r2[ix * ny + iy]:
+                        ok = False
+                if not ok:
+                    continue
+            pr = make_problem(s, g, **mk)
+            if pr["inner_xy"].shape[1] + 1 > max_pieces:
+                continue
+            out.append(pr)
             break
     return out
 

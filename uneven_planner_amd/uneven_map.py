@@ -18,6 +18,31 @@ from .scenes import read_pcd
 HILL_MAP_PARAMS = dict(iter_num=2, map_size_x=10.0, map_size_y=10.0, ellipsoid_x=0.2, ellipsoid_y=0.1,
                        ellipsoid_z=0.1, xy_resolution=0.05, yaw_resolution=0.1, min_cnormal=0.8, max_rho=0.05,
                        gravity=9.81)
+# BASELINE.json configs[4] / SURVEY.md 8c row 5: 1 km^2 at 0.25 m x 64 yaw bins = 1.02e9 cells, 16.4 GB as fp32 cells (replicated per GPU);
+# fBm H = 0.8, seed 7, amplitude <= 15 m, worst-case slope <= 35 deg, wavelengths 2 .. 512 m; ripples of 0.5 m wavelength and 6 cm
+# amplitude inside rough patches 25 .. 75 m across
+KM2_MAP_PARAMS = dict(map_size_x=1000.0, map_size_y=1000.0, xy_resolution=0.25)
+FBM_PARAMS = dict(seed=7, hurst=0.8, lambda_min=2.0, lambda_max=512.0, amplitude=15.0, max_slope_deg=35.0, n_waves=32, rough_amp=0.06,
+                  rough_lambda=0.5, patch_lambda=25.0, rough_threshold=0.62)
+DOWNLOAD_LIMIT_CELLS = 1 << 26      # larger grids keep their cells on the device; the host copy holds occ_r2 only
+
+
+def _fbm(params):
+    q = dict(FBM_PARAMS)
+    if params:
+        q.update(params)
+    return _lib.FbmParams(**{k: (int(v) if k in ("seed", "n_waves") else float(v)) for k, v in q.items()})
+
+
+def fbm_table(params=None):
+    """the wave table the device fill uses (uph_fbm_table): dict of arrays a, kx, ky, ph [n_waves], ripples [4,3], envelope [3,3]"""
+    fp = _fbm(params)
+    t = np.zeros(_lib.FBM_TABLE_DOUBLES)
+    _lib.check(_lib.load().uph_fbm_table(C.byref(fp), _dp(t)), "uph_fbm_table")
+    w = t[:4 * _lib.FBM_MAX_WAVES].reshape(-1, 4)[:fp.n_waves]
+    o = 4 * _lib.FBM_MAX_WAVES
+    return dict(a=w[:, 0].copy(), kx=w[:, 1].copy(), ky=w[:, 2].copy(), ph=w[:, 3].copy(), ripples=t[o:o + 12].reshape(4, 3).copy(),
+                envelope=t[o + 12:o + 21].reshape(3, 3).copy(), rough_amp=fp.rough_amp, rough_threshold=fp.rough_threshold)
 
 
 def _dp(a):
@@ -46,7 +71,10 @@ def gather_slabs(slab, nx, row_elems, world, all_gather):
 
 
 class UnevenMap:
-    def __init__(self, params=None, device=0):
+    def __init__(self, params=None, device=0, storage="f64"):
+        """storage "f64": cells as the reference's doubles; "f32": four floats per cell (configs[4]; lookups widen to double)"""
+        assert storage in ("f64", "f32")
+        self.storage = storage
         self.L = _lib.load()
         _lib.require_device()
         q = dict(HILL_MAP_PARAMS)
@@ -55,7 +83,8 @@ class UnevenMap:
         self.params = q
         self._mp = _lib.MapParams(**{k: (int(v) if k == "iter_num" else float(v)) for k, v in q.items()})
         h = C.c_void_p()
-        _lib.check(self.L.uph_map_create(C.byref(self._mp), int(device), C.byref(h)), "uph_map_create")
+        create = self.L.uph_map_create if storage == "f64" else self.L.uph_map_create_f32
+        _lib.check(create(C.byref(self._mp), int(device), C.byref(h)), "uph_map_create")
         self.h = h
         d = (C.c_int32 * 3)()
         _lib.check(self.L.uph_map_dims(self.h, d), "uph_map_dims")
@@ -134,14 +163,42 @@ class UnevenMap:
         return self
 
     def download(self):
-        cells = np.zeros((self.ncell, 4))
-        cb = np.zeros(self.ncell)
-        occ = np.zeros(self.ncell, dtype=np.int8)
         occ2 = np.zeros(int(self.voxel_num[0] * self.voxel_num[1]), dtype=np.int8)
-        _lib.check(self.L.uph_map_get_cells(self.h, _dp(cells), _dp(cb), occ.ctypes.data_as(C.c_char_p),
+        if self.ncell > DOWNLOAD_LIMIT_CELLS:         # km^2-scale grid: cells stay on the device (get_window serves pieces of it)
+            _lib.check(self.L.uph_map_get_cells(self.h, None, None, None, occ2.ctypes.data_as(C.c_char_p)), "uph_map_get_cells")
+            self.map_buffer = self.c_buffer = self.occ_buffer = self.host = None
+            self.occ_r2_buffer = occ2
+            return
+        cells = np.zeros((self.ncell, 4))
+        occ = np.zeros(self.ncell, dtype=np.int8)
+        cb = np.zeros(self.ncell) if self.storage == "f64" else None
+        _lib.check(self.L.uph_map_get_cells(self.h, _dp(cells), _dp(cb) if cb is not None else None, occ.ctypes.data_as(C.c_char_p),
                                             occ2.ctypes.data_as(C.c_char_p)), "uph_map_get_cells")
+        if cb is None:
+            cb = np.sqrt(1.0 - cells[:, 2] ** 2 - cells[:, 3] ** 2)
         self.map_buffer, self.c_buffer, self.occ_buffer, self.occ_r2_buffer = cells, cb, occ, occ2
         self.host = HostGridView(cells, self.params["map_size_x"], self.params["map_size_y"], self.xy_resolution, self.yaw_resolution)
+
+    def get_window(self, x0, x1, y0, y1):
+        """cells of the xy index window [x0, x1) x [y0, y1) as float64 (x1-x0, y1-y0, nyaw, 4), from the device grid"""
+        out = np.zeros((int(x1) - int(x0), int(y1) - int(y0), int(self.voxel_num[2]), 4))
+        _lib.check(self.L.uph_map_get_window(self.h, int(x0), int(x1), int(y0), int(y1), _dp(out)), "uph_map_get_window")
+        return out
+
+    # ---- analytic fractal terrain (BASELINE.json configs[4]) ---------------------------------------------------------
+    def fill_fbm(self, fbm=None, x0=0, x1=None, download=True):
+        """fill the x-slab [x0, x1) with the analytic fBm terrain (uph_map_fill_fbm): a constructMap-style plane fit per cell on samples of
+        the analytic surface"""
+        fp = _fbm(fbm)
+        _lib.check(self.L.uph_map_fill_fbm(self.h, C.byref(fp), int(x0), int(self.voxel_num[0]) if x1 is None else int(x1)), "uph_map_fill_fbm")
+        if download:
+            self.download()
+        self.map_ready = True
+        return self
+
+    def fill_fbm_sharded(self, fbm, rank, world, all_gather):
+        """the fill sharded like constructMap: rank r fills its x-slab, one all-gather of the slabs (RCCL), every rank imports the whole grid"""
+        return self._sharded(lambda x0, x1: self.fill_fbm(fbm, x0, x1, download=False), rank, world, all_gather)
 
     def cells_device(self):
         """(device pointer, nbytes) of the AoS cell array, for the host framework's RCCL all-gather of x-slabs."""
@@ -152,15 +209,18 @@ class UnevenMap:
     def build_sharded(self, xyz, rank, world, all_gather):
         """constructMap sharded over `world` ranks: rank r fits its x-slab (slab_bounds), then ONE all-gather of the
         slabs (RCCL over xGMI when `all_gather` is torch.distributed.all_gather_into_tensor on CUDA tensors) and every rank
-        imports the complete cell array.  `all_gather(full_tensor, slab_tensor)` works on torch float64 tensors."""
+        imports the complete cell array.  `all_gather(full_tensor, slab_tensor)` works on torch tensors of the storage type."""
+        return self._sharded(lambda x0, x1: self.build(xyz, x0=x0, x1=x1, download=False), rank, world, all_gather)
+
+    def _sharded(self, make_slab, rank, world, all_gather):
         import torch
         nx, ny, nyaw = (int(v) for v in self.voxel_num)
         row = ny * nyaw * 4
         per, x0, x1 = slab_bounds(nx, rank, world)
         dev = torch.device("cuda", self.device)
-        slab = torch.zeros(per * row, dtype=torch.float64, device=dev)
+        slab = torch.zeros(per * row, dtype=torch.float64 if self.storage == "f64" else torch.float32, device=dev)
         if x1 > x0:
-            self.build(xyz, x0=x0, x1=x1, download=False)
+            make_slab(x0, x1)
             _lib.check(self.L.uph_map_export_slab_dev(self.h, x0, x1, C.c_void_p(slab.data_ptr())), "uph_map_export_slab_dev")
         torch.cuda.synchronize(dev)
         full = gather_slabs(slab, nx, row, world, all_gather).contiguous()
