@@ -91,6 +91,15 @@ typedef struct uph_opt_params {
     int32_t mem_size, past, int_K;
 } uph_opt_params;
 
+/* ---- PlanManager parameters of the initial-guess stage: rosparam manager/... (plan_manager.cpp:9-13), values of run_hill.yaml:57-62 */
+typedef struct uph_manager_params {
+    double piece_len;           /* 0.3  */
+    double mean_vel;            /* 0.5  */
+    double init_time_times;     /* 1.2  */
+    double yaw_piece_times;     /* 2.0  */
+    double init_sig_vel;        /* 0.05 */
+} uph_manager_params;
+
 /* ---- one optimizeSE2Traj call.  Matrices are column-major like Eigen::MatrixXd:
  *      init_xy/end_xy = 2x3 {P,V,A columns} -> [Px,Py,Vx,Vy,Ax,Ay]; inner_xy = 2 x n_inner_xy -> [x0,y0,x1,y1,...] */
 typedef struct uph_problem {
@@ -129,6 +138,15 @@ typedef struct uph_result {
 const char* uph_last_error(void);
 int uph_device_count(void);
 const char* uph_version(void);
+
+/* ---- initial guess: PlanManager::rcvWpsCallBack between kino_astar->plan and traj_opt.optimizeSE2Traj (plan_manager.cpp:62-132), for a
+ *      batch of front-end paths.  paths = concatenated poses [x, y, yaw]; path b is poses offsets[b] .. offsets[b+1]-1.  Outputs are the
+ *      optimizeSE2Traj arguments in uph_problem's layout, problem b at init_xy + 6b, init_yaw + 3b, inner_xy + 2*cap_xy*b ([x0,y0,x1,y1,..]),
+ *      inner_yaw + cap_yaw*b; n_inner_* receive the way-point counts.  unwrapped (may be NULL) receives the yaw column after :62-78.
+ *      UPH_ERR_LIMIT when a path needs more than cap_xy / cap_yaw way-points (the counts are still written). */
+int uph_resample_batch(const uph_manager_params* mp, int32_t B, const double* paths, const int64_t* offsets, int32_t cap_xy, int32_t cap_yaw,
+                       double* init_xy, double* end_xy, double* init_yaw, double* end_yaw, double* inner_xy, double* inner_yaw,
+                       int32_t* n_inner_xy, int32_t* n_inner_yaw, double* total_time, double* unwrapped);
 
 /* ---- terrain map */
 int uph_map_create(const uph_map_params* mp, int device, uph_map** out);

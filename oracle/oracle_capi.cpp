@@ -4,6 +4,7 @@
 #include <cstring>
 #include <memory>
 #include "alm.hpp"
+#include "resample.hpp"
 #include "mapbuild.hpp"
 
 using namespace orc;
@@ -388,5 +389,20 @@ void orc_plane_filter(const double* pts, int n, double* cell4) {
 }
 int orc_map_write_csv(void* grid, const char* path) { return writeMapCSV(*(Grid*)grid, path) ? 0 : -1; }
 int orc_map_read_csv(void* grid, const char* path) { return readMapCSV(*(Grid*)grid, path) ? 0 : -1; }
+
+// plan_manager.cpp:62-132 for one path of M poses; inner_xy / inner_yaw sized by the caller (cap entries), counts returned in n2
+void orc_resample(const double* path, int M, const double* mp5, double* init_xy, double* end_xy, double* init_yaw, double* end_yaw, double* inner_xy, double* inner_yaw,
+                  int cap_xy, int cap_yaw, int* n2, double* total_time, double* unwrapped) {
+    orc::ManagerParams mp;
+    mp.piece_len = mp5[0]; mp.mean_vel = mp5[1]; mp.init_time_times = mp5[2]; mp.yaw_piece_times = mp5[3]; mp.init_sig_vel = mp5[4];
+    orc::Resampled r = orc::resamplePath(std::vector<double>(path, path + 3 * (size_t)M), mp);
+    for (int k = 0; k < 6; k++) { init_xy[k] = r.init_xy[k]; end_xy[k] = r.end_xy[k]; }
+    for (int k = 0; k < 3; k++) { init_yaw[k] = r.init_yaw[k]; end_yaw[k] = r.end_yaw[k]; }
+    n2[0] = (int)(r.inner_xy.size() / 2); n2[1] = (int)r.inner_yaw.size();
+    for (int i = 0; i < std::min(n2[0], cap_xy) * 2; i++) inner_xy[i] = r.inner_xy[i];
+    for (int i = 0; i < std::min(n2[1], cap_yaw); i++) inner_yaw[i] = r.inner_yaw[i];
+    *total_time = r.total_time;
+    if (unwrapped) for (int i = 0; i < M; i++) unwrapped[i] = r.yaw_unwrapped[i];
+}
 
 }  // extern "C"

@@ -439,6 +439,27 @@ def lbfgs_rosenbrock(x0, mem_size=8, past=3, g_eps=1e-5, delta=1e-6):
     return r, x, f[0], it.value, ev.value
 
 
+def resample(path, params=None):
+    """plan_manager.cpp:62-132 through the C++ restatement (oracle/resample.hpp): path (M,3) -> the optimizeSE2Traj argument dict
+    (+ "yaw_unwrapped")"""
+    L = lib()
+    q = dict(piece_len=0.3, mean_vel=0.5, init_time_times=1.2, yaw_piece_times=2.0, init_sig_vel=0.05)
+    if params:
+        q.update(params)
+    mp5 = np.array([q["piece_len"], q["mean_vel"], q["init_time_times"], q["yaw_piece_times"], q["init_sig_vel"]])
+    path = _f64(path).reshape(-1, 3)
+    M = path.shape[0]
+    cap = 4096
+    ixy, exy, iyw, eyw = np.zeros(6), np.zeros(6), np.zeros(3), np.zeros(3)
+    oxy, oyw, n2, tt, un = np.zeros(2 * cap), np.zeros(cap), (C.c_int * 2)(), np.zeros(1), np.zeros(M)
+    L.orc_resample.restype = None
+    L.orc_resample.argtypes = [C.POINTER(C.c_double), C.c_int] + [C.POINTER(C.c_double)] * 7 + [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_resample(_dp(path), M, _dp(mp5), _dp(ixy), _dp(exy), _dp(iyw), _dp(eyw), _dp(oxy), _dp(oyw), cap, cap, n2, _dp(tt), _dp(un))
+    assert n2[0] <= cap and n2[1] <= cap
+    return dict(init_xy=ixy.reshape(3, 2).T.copy(), end_xy=exy.reshape(3, 2).T.copy(), inner_xy=oxy[:2 * n2[0]].reshape(-1, 2).T.copy(),
+                init_yaw=iyw, end_yaw=eyw, inner_yaw=oyw[:n2[1]].copy(), total_time=float(tt[0]), yaw_unwrapped=un)
+
+
 def window_oracle(umap, prob, margin=8.0):
     """Checker for grids too large to copy to the host (BASELINE.json configs[4], 1e9 cells): the cells of the xy window around one
     problem, downloaded from the device map `umap` (UnevenMap.get_window), as an OracleGrid of that window's size, and the problem

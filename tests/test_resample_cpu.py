@@ -1,0 +1,85 @@
+"""the initial-guess stage between the front-end and optimizeSE2Traj (plan_manager.cpp:62-132).
+Three independently written forms -- the oracle's C++ restatement in the reference's own two-pass order (oracle/resample.hpp),
+the product's streaming batched routine behind the C-ABI (uph_resample_batch) and the product's numpy mirror (resample.resample_path)
+-- must agree bit for bit, and reproduce answers derived by hand from the reference's lines.  (The reference has no test or fixture
+for this stage and cannot be built here, so there is no golden vector to pin against: "parity unpinned" in oracle/resample.hpp.)"""
+import math
+
+import numpy as np
+import pytest
+
+from uneven_planner_amd import resample as R
+
+KEYS = ("init_xy", "end_xy", "inner_xy", "init_yaw", "end_yaw", "inner_yaw")
+
+
+def same(a, b):
+    return all(np.array_equal(np.asarray(a[k]), np.asarray(b[k])) for k in KEYS) and a["total_time"] == b["total_time"]
+
+
+def paths(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        s = np.array([rng.uniform(-4, 4), rng.uniform(-4, 4), rng.uniform(-math.pi, math.pi)])
+        g = np.array([rng.uniform(-4, 4), rng.uniform(-4, 4), rng.uniform(-math.pi, math.pi)])
+        p = R.hermite_path(s, g, interval=rng.choice([0.03, 0.06, 0.11]))
+        if i % 3 == 0:                 # front-end style yaw column: wrapped into (-pi, pi] with jumps, plus multiples of 2 pi
+            p[:, 2] = np.arctan2(np.sin(p[:, 2]), np.cos(p[:, 2])) + 2 * math.pi * rng.integers(-2, 3, size=p.shape[0])
+        if i % 4 == 1:                 # repeated poses (zero-length segments) and one long jump (several way-points inside one segment)
+            p = np.concatenate([p[:5], p[4:5], p[4:5], p[5::7]])
+        out.append(p)
+    return out
+
+
+def test_three_forms_agree_bit_for_bit(oracle):
+    ps = paths(60, 42)
+    for kw in (dict(), dict(piece_len=0.21, yaw_piece_times=3.0, mean_vel=0.8, init_time_times=1.5, init_sig_vel=0.11)):
+        native = R.resample_batch(ps, cap_xy=4096, cap_yaw=4096, **kw)
+        for p, nat in zip(ps, native):
+            assert same(oracle.resample(p, kw), nat) and same(R.resample_path(p, **kw), nat)
+    # the unwrapped yaw column (:62-78) from the one-pass form equals the reference-order first pass
+    import ctypes as C
+    from uneven_planner_amd import _lib
+    L = _lib.load()
+    p = ps[0]
+    un = np.zeros(p.shape[0])
+    off = np.array([0, p.shape[0]], dtype=np.int64)
+    mp = _lib.ManagerParams(**R.MANAGER_PARAMS)
+    z6, z3, big, n1, t1 = np.zeros(6), np.zeros(3), np.zeros(8192), np.zeros(1, dtype=np.int32), np.zeros(1)
+    dp = lambda a: a.ctypes.data_as(_lib.DP)
+    rc = L.uph_resample_batch(C.byref(mp), 1, dp(np.ascontiguousarray(p)), off.ctypes.data_as(C.POINTER(C.c_int64)), 4096, 4096, dp(z6), dp(z6.copy()), dp(z3), dp(z3.copy()),
+                              dp(big), dp(big.copy()), n1.ctypes.data_as(C.POINTER(C.c_int32)), n1.copy().ctypes.data_as(C.POINTER(C.c_int32)), dp(t1), dp(un))
+    assert rc == 0 and np.array_equal(un, oracle.resample(p)["yaw_unwrapped"])
+    # (the reference's two `while` loops leave a step in [pi/2, 3 pi/2) as it is -- minus 2 pi, then plus 2 pi -- so no bound of pi/2 on the result)
+    assert np.abs(np.diff(un)).max() < 1.5 * math.pi
+
+
+def test_known_answers_derived_by_hand(oracle):
+    # straight line along x in eleven 0.25 m steps (exact in binary): temp_len_pos passes 0.3 on segment 2 (0.5 > 0.3: node at
+    # x = 0.25 + (1 - 0.2/0.25) * 0.25 = 0.3), leaves 0.2, and so on: nodes every 0.3 m up to 2.7; yaw nodes every 0.15 m;
+    # total_time = 2.75 / 0.5 * 1.2 = 6.6
+    p = np.column_stack([0.25 * np.arange(12), np.zeros(12), np.zeros(12)])
+    for r in (oracle.resample(p), R.resample_batch([p])[0], R.resample_path(p)):
+        assert np.allclose(r["inner_xy"][0], 0.3 * np.arange(1, 10), atol=1e-12) and not r["inner_xy"][1].any()
+        assert r["inner_yaw"].shape == (18,) and not r["inner_yaw"].any()
+        assert abs(r["total_time"] - 6.6) < 1e-12
+        assert np.array_equal(r["init_xy"], [[0.0, 0.05, 0.0], [0.0, 0.0, 0.0]]) and np.array_equal(r["end_xy"], [[2.75, 0.05, 0.0], [0.0, 0.0, 0.0]])
+    # yaw column 3.0 -> -3.0 (a +0.283 rad turn through the branch cut): unwrapped to 3.0 -> 3.283..; end heading and velocity follow it
+    p = np.array([[0.0, 0.0, 3.0], [0.2, 0.0, -3.0], [0.4, 0.0, -3.0]])
+    for r in (oracle.resample(p), R.resample_batch([p])[0], R.resample_path(p)):
+        assert abs(r["end_yaw"][0] - (2 * math.pi - 3.0)) < 1e-15 and abs(r["init_yaw"][0] - 3.0) == 0.0
+        assert abs(r["end_xy"][0, 1] - 0.05 * math.cos(2 * math.pi - 3.0)) < 1e-17
+        # yaw nodes at arc length 0.15 (on segment 0, three quarters of the way through the turn) and 0.30 (segment 1, constant)
+        assert np.allclose(r["inner_yaw"], [3.0 + 0.75 * (2 * math.pi - 6.0), 2 * math.pi - 3.0], atol=1e-14)
+        assert np.allclose(r["inner_xy"], [[0.3], [0.0]], atol=1e-15)
+
+
+def test_capacity_overflow_is_reported_with_counts(oracle):
+    from uneven_planner_amd import _lib
+    p = np.column_stack([np.linspace(0, 30, 600), np.zeros(600), np.zeros(600)])      # 30 m: about 100 position way-points > 64
+    with pytest.raises(_lib.UnevenHipError, match="more way-points"):
+        R.resample_batch([p])
+    assert same(R.resample_batch([p], cap_xy=128, cap_yaw=256)[0], oracle.resample(p))
+    with pytest.raises(_lib.UnevenHipError):
+        R.resample_batch([p[:1]])                                                      # a path needs two poses

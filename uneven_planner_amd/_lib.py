@@ -24,6 +24,11 @@ class OptParams(C.Structure):
                 ("mem_size", C.c_int32), ("past", C.c_int32), ("int_K", C.c_int32)]
 
 
+class ManagerParams(C.Structure):
+    _fields_ = [("piece_len", C.c_double), ("mean_vel", C.c_double), ("init_time_times", C.c_double), ("yaw_piece_times", C.c_double),
+                ("init_sig_vel", C.c_double)]
+
+
 class FbmParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("hurst", C.c_double), ("lambda_min", C.c_double), ("lambda_max", C.c_double),
                 ("amplitude", C.c_double), ("max_slope_deg", C.c_double), ("n_waves", C.c_int32), ("rough_amp", C.c_double),
@@ -56,6 +61,7 @@ SYMBOLS = {
     "uph_last_error": (C.c_char_p, []),
     "uph_device_count": (C.c_int, []),
     "uph_version": (C.c_char_p, []),
+    "uph_resample_batch": (C.c_int, [C.POINTER(ManagerParams), _I32, DP, C.POINTER(_I64), _I32, _I32, DP, DP, DP, DP, DP, DP, C.POINTER(_I32), C.POINTER(_I32), DP, DP]),
     "uph_map_create": (C.c_int, [C.POINTER(MapParams), C.c_int, C.POINTER(_VP)]),
     "uph_map_create_f32": (C.c_int, [C.POINTER(MapParams), C.c_int, C.POINTER(_VP)]),
     "uph_map_storage_bytes": (C.c_int, [_VP]),

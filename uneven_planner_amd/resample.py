@@ -97,6 +97,34 @@ def resample_path(init_path, piece_len=0.3, mean_vel=0.5, init_time_times=1.2, y
                 total_time=float(total_time))
 
 
+def resample_batch(paths, cap_xy=64, cap_yaw=128, **kw):
+    """the same stage for a batch of front-end paths through the native routine (uph_resample_batch, csrc/resample_host.cpp): list of
+    (M_i,3) arrays -> list of optimizeSE2Traj argument dicts.  Needs libunevenhip.so (no GPU); raises when a path needs more than
+    cap_xy / cap_yaw way-points (defaults: UPH_MAX_PIECE_XY, UPH_MAX_PIECE_YAW)."""
+    import ctypes as C
+
+    from . import _lib
+    L = _lib.load()
+    mk = dict(MANAGER_PARAMS)
+    mk.update(kw)
+    mp = _lib.ManagerParams(**{k: float(v) for k, v in mk.items()})
+    B = len(paths)
+    arrs = [np.ascontiguousarray(p, dtype=np.float64).reshape(-1, 3) for p in paths]
+    off = np.zeros(B + 1, dtype=np.int64)
+    off[1:] = np.cumsum([a.shape[0] for a in arrs])
+    flat = np.concatenate(arrs, axis=0) if B else np.zeros((0, 3))
+    ixy, exy, iyw, eyw = np.zeros((B, 6)), np.zeros((B, 6)), np.zeros((B, 3)), np.zeros((B, 3))
+    oxy, oyw = np.zeros((B, 2 * max(cap_xy, 1))), np.zeros((B, max(cap_yaw, 1)))
+    nxy, nyw, tt = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32), np.zeros(B)
+    dp = lambda a: a.ctypes.data_as(_lib.DP)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    rc = L.uph_resample_batch(C.byref(mp), B, dp(flat), off.ctypes.data_as(C.POINTER(C.c_int64)), int(cap_xy), int(cap_yaw), dp(ixy), dp(exy), dp(iyw), dp(eyw),
+                              dp(oxy), dp(oyw), ip(nxy), ip(nyw), dp(tt), None)
+    _lib.check(rc, "uph_resample_batch")
+    return [dict(init_xy=ixy[b].reshape(3, 2).T.copy(), end_xy=exy[b].reshape(3, 2).T.copy(), inner_xy=oxy[b, :2 * nxy[b]].reshape(-1, 2).T.copy(),
+                 init_yaw=iyw[b].copy(), end_yaw=eyw[b].copy(), inner_yaw=oyw[b, :nyw[b]].copy(), total_time=float(tt[b])) for b in range(B)]
+
+
 def make_problem(start, goal, **kw):
     """start/goal (x,y,yaw) -> optimizeSE2Traj arguments, through the Hermite stand-in front-end and the resampler."""
     mk = dict(MANAGER_PARAMS)
