@@ -30,6 +30,33 @@ def solve_with_fma_oracle(cells, probs, params=None, grid_kw=None):
     return out
 
 
+def eval_with_fma_oracle(cells, probs, points):
+    """(f, grad, c_xy) of one objective evaluation per problem at the given point, after setup + initScaling, from the oracle rebuilt with
+    -ffp-contract=fast -march=native"""
+    from oracle import oracle_py as O
+    so = "/tmp/liboracle_fma_%d.so" % os.getpid()
+    subprocess.check_call(["g++", "-O3", "-march=native", "-ffp-contract=fast", "-std=c++17", "-fPIC", "-shared", "-o", so,
+                           os.path.join(ROOT, "oracle", "oracle_capi.cpp")])
+    saved = O._LIB
+    O._LIB = None
+    real = O.os.path.join
+    O.os.path.join = lambda *a, _r=real: so if a[-1] == "liboracle.so" else _r(*a)
+    try:
+        g = O.OracleGrid()
+        g.set_cells(cells)
+        out = []
+        for p, x in zip(probs, points):
+            a = O.OracleALM(g)
+            x0 = a.setup(p)
+            a.init_scaling(x0)
+            f, gr, _ = a.eval(x)
+            out.append((f, gr, np.asarray(a.coeffs()[0]).ravel()))
+    finally:
+        O.os.path.join = real
+        O._LIB = saved
+    return out
+
+
 def spread(res_a, res_b, key_cost_a="cost", key_cost_b="cost"):
     dx = np.array([np.abs(a["x"] - b["x"]).max() / np.abs(a["x"]).max() for a, b in zip(res_a, res_b)])
     dc = np.array([abs(a[key_cost_a] - b[key_cost_b]) / abs(a[key_cost_a]) for a, b in zip(res_a, res_b)])

@@ -44,6 +44,36 @@ def test_emu_terrain_eval_scaling(emu, oracle, oracle_grid, hill_problem, small_
         assert rel(s2["scale_cx"], r2["scale_cx"]) < 1e-10
 
 
+def test_per_evaluation_noise_is_at_the_oracles_own_fma_floor(emu, oracle, analytic_cells, small_problems, hill_problem):
+    """What the reduced knot system (Thomas recurrences instead of the reference's banded LU) costs per evaluation: the device program's
+    f / gradient / coefficients differ from the oracle's by no more than the oracle differs from itself when recompiled with FMA
+    contraction (tools/per_eval_noise.py prints the table)."""
+    import sensitivity
+    E.lib().emu_set_lanes(128)
+    probs = [hill_problem] + list(small_problems)
+    g = oracle.OracleGrid()
+    g.set_cells(analytic_cells)
+    pts, plain, dev = [], [], []
+    for i, p in enumerate(probs):
+        a = oracle.OracleALM(g)
+        x0 = a.setup(p)
+        a.init_scaling(x0)
+        st = a.get_state()
+        x = x0 + 0.01 * np.random.default_rng(i).normal(size=x0.size)
+        f, gr, _ = a.eval(x)
+        plain.append((f, gr, np.asarray(a.coeffs()[0]).ravel()))
+        r = emu.run(0, p, x, lam=np.zeros(a.S), mu=np.zeros(6 * a.S), scale_cx=st["scale_cx"], rho=1.0, scale_fx=st["scale_fx"])
+        dev.append((r["f"], r["g"], np.asarray(r["c_xy"]).ravel()))
+        pts.append(x)
+    fma = sensitivity.eval_with_fma_oracle(analytic_cells, probs, pts)
+    noise = lambda other: (np.median([abs(a[0] - b[0]) / abs(a[0]) for a, b in zip(plain, other)]),
+                           np.median([rel(a[1], b[1]) for a, b in zip(plain, other)]), np.median([rel(a[2], b[2]) for a, b in zip(plain, other)]))
+    nd, nf = noise(dev), noise(fma)
+    print("device program vs oracle (f, grad, coeffs)", nd, " oracle(FMA) vs oracle", nf)
+    assert nd[0] <= 4 * nf[0] + 1e-15 and nd[1] <= 4 * nf[1] + 1e-15 and nd[2] <= 4 * nf[2] + 1e-15
+    assert nd[1] < 1e-13 and nd[2] < 1e-13
+
+
 def test_emu_f32_cell_storage_equals_oracle_on_rounded_cells(oracle, analytic_cells, hill_problem):
     """BASELINE.json configs[4]'s fp32 mode: cells stored as floats, widened on load, fp64 arithmetic -- so the lookups and the
     objective equal the oracle's on the float-rounded grid to rounding error, not to fp32 precision"""
