@@ -44,6 +44,12 @@ typedef struct uph_ctx uph_ctx;   /* optimiser context bound to one map, one dev
 #define UPH_ERR_NO_DEVICE (-3) /* no gfx950 device visible                        */
 #define UPH_ERR_LIMIT (-4)     /* problem exceeds a compiled limit (UPH_MAX_*)    */
 
+/* uph_result.ret_code beyond the reference's 0 / 1 / 2: */
+#define UPH_RET_STOPPED 3      /* test hook only: the ALM loop was stopped by uph_batch_alm_passes' pass cap                          */
+#define UPH_RET_UNSUPPORTED 4  /* the problem lies outside the compiled limits (no inner way-point in a block, i.e. a goal closer than
+                                  one piece length; more than UPH_MAX_PIECE_* pieces; piece_yaw < piece_xy): not solved, outputs untouched,
+                                  last_lbfgs_ret = the UPH_ERR_* reason.  The other problems of the batch are solved normally.            */
+
 #define UPH_MAX_PIECE_XY 64    /* Nxy  <= 64  (19 m at piece_len 0.3)  */
 #define UPH_MAX_PIECE_YAW 128  /* Nyaw <= 128                          */
 #define UPH_MAX_MEM 256        /* L-BFGS history length                */
@@ -117,7 +123,7 @@ typedef struct uph_problem {
  *      c_xy[6*piece_xy*2] row-major (row 6i+k = t^k coefficient of piece i, se2traj.hpp:570), c_yaw[6*piece_yaw];
  *      hx[S], gx[6*S], lambda[S], mu[6*S] in the reference's constraint order (alm_traj_opt.cpp:705-708), S = piece_xy*(int_K+1) */
 typedef struct uph_result {
-    int32_t ret_code;           /* 0 ok, 1 L-BFGS hard error, 2 ALM hit max_iter (alm_traj_opt.cpp:176,252,267) */
+    int32_t ret_code;           /* 0 ok, 1 L-BFGS hard error, 2 ALM hit max_iter (alm_traj_opt.cpp:176,252,267); UPH_RET_* above */
     int32_t alm_iters, lbfgs_iters, evals, last_lbfgs_ret;
     double cost;                /* inner_cost of the last L-BFGS call */
     double jerk_cost;           /* minco_se2.getTrajJerkCost() of the last evaluated trajectory */
@@ -200,7 +206,8 @@ int uph_map_build_stats(uph_map* m, double* kernel_ms, int64_t* cell_iters, int6
 int uph_ctx_create(uph_map* m, const uph_opt_params* p, uph_ctx** out);
 void uph_ctx_destroy(uph_ctx* c);
 /* rho is a member that persists across solves in the reference (alm_traj_opt.cpp:16, alm_traj_opt.h:137): every problem of a
- * batch starts from the context's rho; after a batch the context's rho becomes the final rho of the LAST problem. */
+ * batch starts from the context's rho.  After a solve of ONE problem the context's rho is that problem's final rho (the reference's
+ * behaviour over consecutive calls); a batch of B > 1 independent problems leaves it unchanged (each result carries its rho_final). */
 /* lanes of one workgroup that cooperate on ONE trajectory: 64, 128 or 256 (one, two or four wave64); 0 = automatic (default):
  * 128 lanes with up to four workgroups per CU from 2304 problems (throughput), 256 lanes below (latency).  Takes effect at the next
  * upload.  Results do not depend on the choice beyond the summation order of the block reductions. */
@@ -215,7 +222,9 @@ int uph_ctx_get_rho(uph_ctx* c, double* rho);
 int uph_ctx_set_trace(uph_ctx* c, int32_t cap);
 int uph_ctx_get_trace(uph_ctx* c, double* out);
 
-/* blocking: upload + solve + download.  B = 1 is one ALMTrajOpt::optimizeSE2Traj call. */
+/* blocking: upload + solve + download.  B = 1 is one ALMTrajOpt::optimizeSE2Traj call.  A problem outside the compiled limits does not fail
+ * the batch: its result carries ret_code UPH_RET_UNSUPPORTED and the others are solved; only a batch without any supported problem
+ * returns UPH_ERR_INVALID / UPH_ERR_LIMIT. */
 int uph_optimize_batch(uph_ctx* c, int32_t B, const uph_problem* probs, uph_result* results);
 /* split form (inputs resident in HBM before the timed region): upload -> solve (kernel only, blocking) -> download */
 int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs);

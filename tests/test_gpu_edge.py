@@ -119,3 +119,32 @@ def test_trajectory_leaving_the_map(devmap, oracle, oracle_grid):
     x0 = a.setup(p)
     fo, go, _ = a.eval(x0)
     assert abs(f[0] - fo) / abs(fo) < 1e-9 and rel(go, g[0]) < 1e-9
+
+
+def test_unsupported_problem_does_not_fail_its_neighbours(analytic_cells):
+    """a goal closer than one piece length (no inner position way-point; the reference would solve a single piece) or a path beyond
+    UPH_MAX_PIECE_XY gets ret_code UPH_RET_UNSUPPORTED; the other problems of the batch are solved exactly as they are alone"""
+    import uneven_planner_amd as U
+    from uneven_planner_amd import resample, scenes
+    m = U.UnevenMap()
+    m.set_cells(analytic_cells)
+    good = scenes.random_problems(3, seed0=2100, dmin=3.0, dmax=5.0)
+    short = resample.make_problem((0.0, 0.0, 0.3), (0.2, 0.1, 0.5))
+    assert short["inner_xy"].shape[1] == 0
+    long_ = resample.resample_path(np.column_stack([np.linspace(-4.5, 4.5, 400), np.linspace(-4.4, 4.4, 400) ** 3 / 20.0, np.zeros(400)]), piece_len=0.12)
+    assert long_["inner_xy"].shape[1] + 1 > 64
+    opt = U.ALMTrajOpt(m)
+    opt.set_rho(1.0)
+    out = opt.optimize_batch([good[0], short, good[1], long_, good[2]])
+    assert [o["ret"] for o in out][1::2] == [4, 4] and out[1]["last_lbfgs_ret"] == -1 and out[3]["last_lbfgs_ret"] == -4
+    alone = U.ALMTrajOpt(m)
+    alone.set_rho(1.0)
+    ref = alone.optimize_batch(good)
+    for a, b in zip(ref, out[0::2]):
+        assert a["ret"] == b["ret"] and a["cost"] == b["cost"] and np.array_equal(a["x"], b["x"])
+    st = opt.stats()
+    assert st["evals"] == sum(o["evals"] for o in out)            # the placeholders' work is not counted
+    with pytest.raises(U._lib.UnevenHipError):
+        opt.eval_batch(None)                                      # packed-array hooks need a clean batch
+    with pytest.raises(U._lib.UnevenHipError):
+        U.ALMTrajOpt(m).optimize_batch([short])                   # nothing solvable in the batch: an error, as before

@@ -157,7 +157,10 @@ def test_rho_persists_across_solves(dev, small_problems):
     assert rho1 > 1.0
     opt.optimizeSE2Traj(p["init_xy"], p["end_xy"], p["inner_xy"], p["init_yaw"], p["end_yaw"], p["inner_yaw"], p["total_time"])
     assert opt.get_rho() >= rho1
+    # a batch of independent problems has no "next call": it starts every problem from the context's rho and leaves it unchanged
     opt.set_rho(1.0)
+    out = opt.optimize_batch(small_problems[:3])
+    assert opt.get_rho() == 1.0 and all(o["rho_final"] > 1.0 for o in out)
 
 
 def test_batch_equals_single(dev, small_problems):

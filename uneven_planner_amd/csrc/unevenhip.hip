@@ -471,6 +471,8 @@ struct uph_ctx {
     size_t lds_bytes = 0;                   // dynamic LDS of the main launch (largest footprint among the trajectories below the residency limit)
     size_t lds_big = 0;                     // ... and of the oversize class, launched concurrently on stream2 (0 = no such class)
     int n_main = 0;                         // order[0, n_main) main class, order[n_main, B) oversize class
+    std::vector<int> rejected;              // per problem: 0, or the status code that made it unsupported (solved as a placeholder, reported as UPH_RET_UNSUPPORTED)
+    int n_rejected = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev2 = nullptr;
     std::vector<size_t> fp_bytes;           // per-trajectory LDS footprint
@@ -677,6 +679,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     const int K1 = c->P.int_K + 1, mem = c->P.mem_size;
     c->B = 0;                       // the context holds no batch until this upload has succeeded as a whole
+    int first_rj = 0;
     c->desc.assign(B, TrajDesc());
     int64_t on = 0, os = 0, ocx = 0, ocy = 0, oh = 0;
     size_t lds_d = 0;
@@ -686,12 +689,32 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     c->lanes = c->lanes_forced ? c->lanes_forced : (B >= 2304 ? 128 : 256);
     c->wps = c->wps_forced ? c->wps_forced : ((B >= 512) ? 2 : 1);
     c->fp_bytes.assign(B, 0);
+    // A problem outside the compiled limits (no inner way-point in a block: a goal closer than one piece length; more pieces than
+    // UPH_MAX_PIECE_*; fewer yaw pieces than position pieces) does not fail its neighbours: a two-piece placeholder takes its slot and
+    // its result carries ret_code UPH_RET_UNSUPPORTED.  Only a batch with no supported problem at all is an error.
+    static const double ph_inner_xy[2] = {0.3, 0.0}, ph_inner_yaw[1] = {0.0};
+    uph_problem placeholder;
+    std::memset(&placeholder, 0, sizeof(placeholder));
+    placeholder.n_inner_xy = 1; placeholder.n_inner_yaw = 1; placeholder.inner_xy = ph_inner_xy; placeholder.inner_yaw = ph_inner_yaw;
+    placeholder.init_xy[2] = 0.05; placeholder.end_xy[0] = 0.6; placeholder.end_xy[2] = 0.05; placeholder.total_time = 1.44;
+    std::vector<const uph_problem*> pp(B);
+    c->rejected.assign(B, 0); c->n_rejected = 0;
+    std::string why;
     for (int b = 0; b < B; b++) {
-        const uph_problem& pr = probs[b];
+        const uph_problem& q = probs[b];
+        int rj = 0;
+        const char* msg = nullptr;
+        if (q.n_inner_xy < 1 || q.n_inner_yaw < 1 || !q.inner_xy || !q.inner_yaw) { rj = UPH_ERR_INVALID; msg = "uph_batch_upload: a problem needs at least one inner way-point per block"; }
+        else if (q.n_inner_xy + 1 > UPH_MAX_PIECE_XY || q.n_inner_yaw + 1 > UPH_MAX_PIECE_YAW) { rj = UPH_ERR_LIMIT; msg = "uph_batch_upload: piece count exceeds UPH_MAX_PIECE_*"; }
+        else if (q.n_inner_yaw < q.n_inner_xy) { rj = UPH_ERR_INVALID; msg = "uph_batch_upload: piece_yaw < piece_xy (the reference indexes yaw_minco.T1 with the xy piece index, alm_traj_opt.cpp:749)"; }
+        c->rejected[b] = rj;
+        pp[b] = rj ? &placeholder : &q;
+        if (rj) { if (!c->n_rejected) { why = msg; first_rj = rj; } c->n_rejected++; }
+    }
+    if (c->n_rejected == B) { c->rejected.clear(); c->n_rejected = 0; setError(why); return first_rj; }
+    for (int b = 0; b < B; b++) {
+        const uph_problem& pr = *pp[b];
         const int Nxy = pr.n_inner_xy + 1, Nyaw = pr.n_inner_yaw + 1;
-        if (pr.n_inner_xy < 1 || pr.n_inner_yaw < 1 || !pr.inner_xy || !pr.inner_yaw) { setError("uph_batch_upload: a problem needs at least one inner way-point per block"); return UPH_ERR_INVALID; }
-        if (Nxy > UPH_MAX_PIECE_XY || Nyaw > UPH_MAX_PIECE_YAW) { setError("uph_batch_upload: piece count exceeds UPH_MAX_PIECE_*"); return UPH_ERR_LIMIT; }
-        if (Nyaw < Nxy) { setError("uph_batch_upload: piece_yaw < piece_xy (the reference indexes yaw_minco.T1 with the xy piece index, alm_traj_opt.cpp:749)"); return UPH_ERR_INVALID; }
         TrajDesc& t = c->desc[b];
         std::memset(&t, 0, sizeof(t));
         t.Nxy = Nxy; t.Nyaw = Nyaw; t.n = 2 * pr.n_inner_xy + pr.n_inner_yaw + 1; t.S = Nxy * K1;
@@ -721,7 +744,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     // x0 = [tau | Pxy | Pyaw]  (alm_traj_opt.cpp:206-216)
     std::vector<double> x0(on);
     for (int b = 0; b < B; b++) {
-        const uph_problem& pr = probs[b];
+        const uph_problem& pr = *pp[b];
         double* x = x0.data() + c->desc[b].off_x;
         x[0] = logC2(pr.total_time);
         for (int i = 0; i < 2 * pr.n_inner_xy; i++) x[1 + i] = pr.inner_xy[i];
@@ -736,7 +759,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     {
         std::vector<double> cost(B);
         for (int b = 0; b < B; b++) {
-            const uph_problem& pr = probs[b];
+            const uph_problem& pr = *pp[b];
             double turn = 0.0, prev = pr.init_yaw[0];
             for (int i = 0; i < pr.n_inner_yaw; i++) { turn += std::fabs(pr.inner_yaw[i] - prev); prev = pr.inner_yaw[i]; }
             turn += std::fabs(pr.end_yaw[0] - prev);
@@ -797,13 +820,14 @@ int uph_batch_solve(uph_ctx* c) {
     if (r != UPH_OK) return r;
     c->last_evals = c->last_sample_evals = c->last_iters = c->last_hist_bytes = 0;
     for (int b = 0; b < c->B; b++) {
+        if (c->rejected[b]) continue;
         const TrajState& s = c->state_host[b];
         c->last_evals += s.evals;
         c->last_sample_evals += (int64_t)s.evals * c->desc[b].S;
         c->last_iters += s.lbfgs_iters;
         c->last_hist_bytes += s.hist_reads * 8;
     }
-    c->rho = c->state_host[c->B - 1].rho;
+    if (c->B == 1 && !c->rejected[0]) c->rho = c->state_host[0].rho;      // one optimizeSE2Traj call: rho persists into the next (Q7).  A batch has no "next": unchanged
     return UPH_OK;
 }
 
@@ -843,6 +867,11 @@ int uph_batch_download(uph_ctx* c, uph_result* results) {
         const TrajDesc& t = c->desc[b];
         const TrajState& s = c->state_host[b];
         uph_result& o = results[b];
+        if (c->rejected[b]) {             // the slot ran a placeholder: nothing of it is the caller's (arrays are left untouched)
+            o.ret_code = UPH_RET_UNSUPPORTED; o.alm_iters = o.lbfgs_iters = o.evals = 0; o.last_lbfgs_ret = c->rejected[b];
+            o.cost = o.jerk_cost = o.piece_T_xy = o.piece_T_yaw = 0.0; o.rho_final = c->rho; o.scale_fx = 1.0;
+            continue;
+        }
         o.ret_code = s.ret_code; o.alm_iters = s.alm_iters; o.lbfgs_iters = s.lbfgs_iters; o.evals = s.evals; o.last_lbfgs_ret = s.last_lbfgs_ret;
         o.cost = s.f; o.jerk_cost = s.jerk_cost; o.piece_T_xy = s.T_xy; o.piece_T_yaw = s.T_yaw; o.rho_final = s.rho; o.scale_fx = s.scale_fx;
         if (o.x_final) std::memcpy(o.x_final, x.data() + t.off_x, 8 * t.n);
@@ -874,6 +903,7 @@ int uph_optimize_batch(uph_ctx* c, int32_t B, const uph_problem* probs, uph_resu
 }
 
 int uph_batch_set_state(uph_ctx* c, const double* lambda, const double* mu, const double* scale_cx, const double* scale_fx, const double* rho) {
+    if (c && c->n_rejected) { setError("packed-array hooks need a batch without unsupported problems (uph_result.ret_code == UPH_RET_UNSUPPORTED)"); return UPH_ERR_INVALID; }
     if (!c || c->B <= 0) { setError("uph_batch_set_state: no batch uploaded"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     std::vector<double> dual(7 * c->sum_S), scl(7 * c->sum_S);
@@ -903,6 +933,7 @@ int uph_batch_set_state(uph_ctx* c, const double* lambda, const double* mu, cons
 }
 
 int uph_eval_batch(uph_ctx* c, const double* x_packed, double* f, double* grad_packed, int32_t repeat) {
+    if (c && c->n_rejected) { setError("packed-array hooks need a batch without unsupported problems (uph_result.ret_code == UPH_RET_UNSUPPORTED)"); return UPH_ERR_INVALID; }
     if (!c || c->B <= 0 || repeat < 1) { setError("uph_eval_batch: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     if (x_packed) HIPCHK(hipMemcpy(c->d_x.p, x_packed, 8 * c->sum_n, hipMemcpyHostToDevice));
@@ -945,6 +976,7 @@ int uph_report_batch(uph_ctx* c, double* out7) {
 static void collectSolveStats(uph_ctx* c) {
     c->last_evals = c->last_sample_evals = c->last_iters = c->last_hist_bytes = 0;
     for (int b = 0; b < c->B; b++) {
+        if (c->rejected[b]) continue;
         const TrajState& s = c->state_host[b];
         c->last_evals += s.evals;
         c->last_sample_evals += (int64_t)s.evals * c->desc[b].S;
@@ -953,6 +985,7 @@ static void collectSolveStats(uph_ctx* c) {
     }
 }
 int uph_batch_set_x(uph_ctx* c, const double* x_packed) {
+    if (c && c->n_rejected) { setError("packed-array hooks need a batch without unsupported problems (uph_result.ret_code == UPH_RET_UNSUPPORTED)"); return UPH_ERR_INVALID; }
     if (!c || c->B <= 0 || !x_packed) { setError("uph_batch_set_x: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(c->d_x.p, x_packed, 8 * c->sum_n, hipMemcpyHostToDevice));
@@ -973,6 +1006,7 @@ int uph_batch_alm_passes(uph_ctx* c, int32_t max_passes) {
 // as the reference holds it -- lm_s / lm_y column j of trajectory b at hist[off_b + j*n] with off_b = mem * sum_{b' < b} n_b', lm_ys
 // [B][mem] --; scal5 [B][5] = step, fx, k, end, bound.  x is the resident x (uph_batch_set_x).
 int uph_batch_set_lbfgs_state(uph_ctx* c, const double* g, const double* d, const double* pf, const double* lm_s, const double* lm_y, const double* lm_ys, const double* scal5) {
+    if (c && c->n_rejected) { setError("packed-array hooks need a batch without unsupported problems (uph_result.ret_code == UPH_RET_UNSUPPORTED)"); return UPH_ERR_INVALID; }
     if (!c || c->B <= 0 || !g || !d || !pf || !lm_s || !lm_y || !lm_ys || !scal5) { setError("uph_batch_set_lbfgs_state: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(c->device));
     const int mem = c->P.mem_size;
