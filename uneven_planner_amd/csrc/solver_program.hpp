@@ -35,7 +35,7 @@ namespace uph {
 
 // scatter batch widths (LDS reads in flight per lane): xy blocks hold K + 1 = 17 records, yaw candidates ~40
 #ifndef UPH_SC_XB
-#define UPH_SC_XB 17
+#define UPH_SC_XB 9
 #endif
 #ifndef UPH_SC_YB
 #define UPH_SC_YB 10
@@ -548,45 +548,63 @@ struct Solver {
             for (int j = 0; j <= K; j++) { bt[Nxy + 1 + j] = s1; s1 += step; }
         }
     }
-    // fold the records of samples [s0, s0+cnt) into G: one lane per output element -- (xy piece, k, dim) and (yaw piece, k) --
-    // each summing the contributions of its <= K+1 (xy) or <= 4(K+1) candidate (yaw) samples in slot order (fixed order, no
-    // atomics).  LDS reads go out in batches so that they overlap.
+    // fold the records of samples [s0, s0+cnt) into G (fixed summation order, no atomics).  The xy outputs and the yaw outputs go to
+    // DIFFERENT waves so that neither wave runs both bodies: lanes [0, XYL) own (xy piece, dim, k-pair) -- three lanes per (piece,
+    // dim), each summing its two k over the piece's <= K+1 samples in slot order -- and the lanes after them own (yaw piece, k-pair),
+    // each summing its two record fields over the candidate slots whose tag names its piece.  XYL is a multiple of the wave size.
+    // Every LDS operand is read at base + constant without clamping: reads next to a piece's slots land in neighbouring words of the
+    // same allocation (wtab sits right before rec) and are discarded by the selects.
     UPH_HD void scatterChunk(int s0, int cnt) {
         const int K1 = K + 1;
         const float xr = (float)Nxy / (float)Nyaw;          // xy pieces per yaw piece
         const int i0 = s0 / K1, i1 = (s0 + cnt - 1) / K1;
-        const int nxyt = 12 * (i1 - i0 + 1);
+        const int nxyt = 6 * (i1 - i0 + 1);
+        const int XYL = (nxyt + 63) & ~63;
         // yaw pieces that can receive samples of this chunk: from the first to the last sample's piece (monotone up to round-off) +-1
         int m0 = rtag[0] - 1, m1 = rtag[cnt - 1] + 1;
         if (m0 < 0) m0 = 0;
         if (m1 > Nyaw - 1) m1 = Nyaw - 1;
-        wg.pfor(nxyt + 6 * (m1 - m0 + 1), [&](int t) {
-            if (t < nxyt) {
-                const int i = i0 + t / 12, r = t % 12, q = r >> 1, dd = r & 1;
-                int ja = i * K1 - s0, jb = ja + K1;          // slots of this piece inside the chunk
-                const int jo = ja;                           // slot - jo = the sample's in-piece index j
-                if (ja < 0) ja = 0;
-                if (jb > cnt) jb = cnt;
-                // every operand of a batch is read at base + constant (no per-element clamping or address arithmetic); reads past the
-                // piece's last slot land in neighbouring LDS words of the same allocation and are discarded by the selects below
-                const double* r0 = rec + dd * CHP + ja;      // grad_p[dd]; grad_v[dd] two rows on, grad_a[dd] four
-                const double* w = wtab + 6 * (ja - jo);      // powers of s1(j) at w[6 * (slot - ja) + k]
-                const int q1 = q >= 1 ? q - 1 : 0, q2 = q >= 2 ? q - 2 : 0;
-                const double c1 = (double)q, c2 = (double)(q * (q - 1));      // beta1_q = q s1^(q-1), beta2_q = q (q-1) s1^(q-2)
-                double a = 0.0;
-                for (int len = jb - ja; len > 0; len -= UPH_SC_XB, r0 += UPH_SC_XB, w += 6 * UPH_SC_XB) {
-                    double e0[UPH_SC_XB], e1[UPH_SC_XB], e2[UPH_SC_XB], w0[UPH_SC_XB], w1[UPH_SC_XB], w2[UPH_SC_XB];
+#ifdef UPH_SC_TEST          // timing experiment only (wrong results): 1 = xy part alone, 2 = yaw part alone
+        wg.pfor(UPH_SC_TEST == 1 ? XYL : XYL + 3 * (m1 - m0 + 1), [&](int t) {
+            if (UPH_SC_TEST == 2 && t < XYL) return;
+#else
+        wg.pfor(XYL + 3 * (m1 - m0 + 1), [&](int t) {
+#endif
+            if (t < XYL) {
+                if (t >= nxyt) return;
+                const int pi = t / 6, r = t - 6 * pi, dd = r & 1, kp = r >> 1;      // r = 2 kp + dd
+                const int i = i0 + pi;
+                const int ja = i * K1 - s0;                  // slot of the piece's sample j = 0 (negative when the piece began in the previous chunk)
+                const int jlo = ja < 0 ? -ja : 0, jhi = cnt - ja < K1 ? cnt - ja : K1;      // the piece's samples inside this chunk: j in [jlo, jhi)
+                const double* r0 = rec + dd * CHP + ja;      // grad_p[dd] of sample j at r0[j]; grad_v[dd] two rows on, grad_a[dd] four
+                // k = 2 kp and 2 kp + 1: beta0_k = s^k, beta1_k = k s^(k-1), beta2_k = k (k-1) s^(k-2) (alm_traj_opt.cpp:738-740) from the
+                // power table; for kp = 0 the absent powers are read at index 0 and meet zero factors
+                const int k0 = 2 * kp, k1 = k0 + 1;
+                const int pa = k0 >= 2 ? k0 - 2 : 0, pb = k0 >= 1 ? k0 - 1 : 0;
+                const double c1a = (double)k0, c2a = (double)(k0 * (k0 - 1)), c1b = (double)k1, c2b = (double)(k1 * k0);
+                double a0 = 0.0, a1 = 0.0;
+                const double* w = wtab;
+#pragma unroll 1
+                for (int jb = 0; jb < K1; jb += UPH_SC_XB) {
+                    double e0[UPH_SC_XB], e1[UPH_SC_XB], e2[UPH_SC_XB], pA[UPH_SC_XB], pB[UPH_SC_XB], pC[UPH_SC_XB], pD[UPH_SC_XB];
 #pragma unroll
                     for (int u = 0; u < UPH_SC_XB; u++) {
-                        e0[u] = r0[u]; e1[u] = r0[2 * CHP + u]; e2[u] = r0[4 * CHP + u];
-                        w0[u] = w[6 * u + q]; w1[u] = w[6 * u + q1]; w2[u] = w[6 * u + q2];
+                        const int j = jb + u;
+                        e0[u] = r0[j]; e1[u] = r0[2 * CHP + j]; e2[u] = r0[4 * CHP + j];
+                        pA[u] = w[6 * j + pa]; pB[u] = w[6 * j + pb]; pC[u] = w[6 * j + k0]; pD[u] = w[6 * j + k1];
                     }
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_XB; u++) a += u < len ? (w0[u] * e0[u] + (c1 * w1[u]) * e1[u] + (c2 * w2[u]) * e2[u]) : 0.0;
+                    for (int u = 0; u < UPH_SC_XB; u++) {
+                        const int j = jb + u;
+                        const bool in = j >= jlo && j < jhi;
+                        a0 += in ? (pC[u] * e0[u] + (c1a * pB[u]) * e1[u] + (c2a * pA[u]) * e2[u]) : 0.0;
+                        a1 += in ? (pD[u] * e0[u] + (c1b * pC[u]) * e1[u] + (c2b * pB[u]) * e2[u]) : 0.0;
+                    }
                 }
-                Gxy[12 * i + r] += a;
+                Gxy[12 * i + 2 * k0 + dd] += a0;
+                Gxy[12 * i + 2 * k1 + dd] += a1;
             } else {
-                const int tt = t - nxyt, m = m0 + tt / 6, k = tt % 6;
+                const int tt = t - XYL, mi = tt / 3, kp = tt - 3 * mi, m = m0 + mi;
                 // candidate slots: sample (i, j) sits at time (i + j / K) Txy, yaw piece m covers [m, m + 1) Tyaw = [m, m + 1) (Nxy / Nyaw) Txy.
                 // The bounds are formed in float and widened by three slots each way (float error <= 1 slot, a sample whose
                 // accumulated time lands an ulp across a yaw boundary <= 1 slot); the tag test below decides membership exactly.
@@ -598,18 +616,23 @@ struct Solver {
                 if (sa < 0) sa = 0;
                 if (sb > cnt) sb = cnt;
                 if (sb < sa) sb = sa;
-                const double* rv = rec + (6 + k) * CHP + sa;
+                const double* rv = rec + (6 + 2 * kp) * CHP + sa;
                 const int* tg = rtag + sa;
-                double a = 0.0;
+                double a0 = 0.0, a1 = 0.0;
                 for (int len = sb - sa; len > 0; len -= UPH_SC_YB, rv += UPH_SC_YB, tg += UPH_SC_YB) {
                     int tg_[UPH_SC_YB];
-                    double vv[UPH_SC_YB];
+                    double v0[UPH_SC_YB], v1[UPH_SC_YB];
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_YB; u++) { tg_[u] = tg[u]; vv[u] = rv[u]; }
+                    for (int u = 0; u < UPH_SC_YB; u++) { tg_[u] = tg[u]; v0[u] = rv[u]; v1[u] = rv[CHP + u]; }
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_YB; u++) a += ((u < len) && (tg_[u] == m)) ? vv[u] : 0.0;
+                    for (int u = 0; u < UPH_SC_YB; u++) {
+                        const bool in = (u < len) && (tg_[u] == m);
+                        a0 += in ? v0[u] : 0.0;
+                        a1 += in ? v1[u] : 0.0;
+                    }
                 }
-                Gyaw[6 * m + k] += a;
+                Gyaw[6 * m + 2 * kp] += a0;
+                Gyaw[6 * m + 2 * kp + 1] += a1;
             }
         });
     }
