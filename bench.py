@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU per step (hill, default 8192) / in total (km2, default 4096)")
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU per step (hill, default 16384) / in total (km2, default 4096)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU oracle for cpu_baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the penalty-kernel and small-batch measurements (profiling runs)")
@@ -63,7 +63,7 @@ def main():
     args = ap.parse_args()
     km2 = args.workload == "km2"
     if not args.batch:
-        args.batch = 4096 if km2 else 8192
+        args.batch = 4096 if km2 else 16384
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -156,8 +156,8 @@ def main():
                        "M_traj_evals_per_s": len(pp) * R / ms / 1e3, "samples_per_traj": S / len(pp), "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
             del ev
         extras["penalty_kernel"] = pk
-        # the batch sizes BASELINE.json names (configs[2]: 256, configs[4]: 4096), same scene and protocol, one warm-up + three solves each
-        for Bx in (256, 4096):
+        # the batch sizes BASELINE.json names (configs[2]: 256, configs[4]: 4096) and the earlier rounds' 8192, same scene and protocol, one warm-up + three solves each
+        for Bx in (256, 4096, 8192):
             if Bx >= args.batch:
                 continue
             o2 = U.ALMTrajOpt(m)

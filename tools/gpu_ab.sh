@@ -5,7 +5,7 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 for v in "$@"; do
   if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
-  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  timeout 300 python bench.py --batch 8192 --steps 4 --warmup 1 --no-cpu > $OUT/bench_$v.json 2> $OUT/bench_$v.err
   python - $OUT/bench_$v.json $v <<'PY'
 import json, sys
 try:

@@ -215,11 +215,13 @@ struct DevWG {
                 yr[slot][NQ - 1] = *(const __attribute__((address_space(1))) double*)(row + 16 + NPAD * 8 + 512 * (NQ - 1) + l8);
             }
         };
+        // explicit fma chains: the contraction the compiler would pick for a*b + c*d is not unique (fma(a,b,c*d) or fma(c,d,a*b)) and was
+        // observed to change with the unroll depth, i.e. the results depended on PF at rounding level
         auto rowDot = [&](const double* a, const double* b_) {
             if (NQ == 1) return a[0] * b_[0];
-            if (NQ == 2) return a[0] * b_[0] + a[1] * b_[1];
-            if (NQ == 3) return (a[0] * b_[0] + a[1] * b_[1]) + a[2] * b_[2];
-            return (a[0] * b_[0] + a[1] * b_[1]) + (a[2 % NQ] * b_[2 % NQ] + a[3 % NQ] * b_[3 % NQ]);
+            if (NQ == 2) return fma(a[1], b_[1], a[0] * b_[0]);
+            if (NQ == 3) return fma(a[2], b_[2], fma(a[1], b_[1], a[0] * b_[0]));
+            return fma(a[1], b_[1], a[0] * b_[0]) + fma(a[3 % NQ], b_[3 % NQ], a[2 % NQ] * b_[2 % NQ]);
         };
         // Steady-state groups of PF steps carry no conditionals: every step re-fills its ring slot unconditionally (all m ring
         // rows exist, so running a few rows past `bound` is harmless), which lets the ring live in fixed registers with exact
@@ -228,14 +230,14 @@ struct DevWG {
             const double al = divByStored(waveSum(rowDot(sr[u], dr)), ysr[u], rysr[u]);
             al_lds[i] = al;                                     // (uniform address and value: one fire-and-forget LDS write)
 #pragma unroll
-            for (int q = 0; q < NQ; q++) dr[q] += (-al) * yr[u][q];
+            for (int q = 0; q < NQ; q++) dr[q] = fma(-al, yr[u][q], dr[q]);
         };
         auto step2 = [&](int u, int i) {
             const double alpha = al_lds[bound - 1 - i];        // broadcast read, issued a whole reduction ahead of its use
             const double beta = divByStored(waveSum(rowDot(yr[u], dr)), ysr[u], rysr[u]);
             const double a = alpha - beta;
 #pragma unroll
-            for (int q = 0; q < NQ; q++) dr[q] += a * sr[u][q];
+            for (int q = 0; q < NQ; q++) dr[q] = fma(a, sr[u][q], dr[q]);
         };
         // compiler fence that consumes the updated direction: the step's arithmetic cannot sink below it, the next loads cannot rise above it
         auto pin = [&]() {
@@ -284,7 +286,7 @@ struct DevWG {
         // g . d for the next line search, while d is still in registers
         double gd = 0.0;
 #pragma unroll
-        for (int q = 0; q < NQ; q++) { const int e = eidx(q); if (e < n) { d[e] = dr[q]; gd += g[e] * dr[q]; } }
+        for (int q = 0; q < NQ; q++) { const int e = eidx(q); if (e < n) { d[e] = dr[q]; gd = fma(g[e], dr[q], gd); } }
         gd = waveSum(gd);
         if (lane == 0) *dg_out = gd;
     }
