@@ -17,3 +17,8 @@ print('max total cycles', cy[:, 6].max(), ' => clock MHz ~', cy[:, 6].max() / (s
 for k, nme in enumerate(names[:6]):
     print('%-28s %5.1f %%   cycles/eval %9.0f' % (nme, 100 * cy[:, k].sum() / tot, cy[:, k].sum() / st['evals']))
 print('eval end -> twoloop start cycles/eval %9.0f' % (cy[:, 7].sum() / st['evals']))
+# packing: sum of workgroup cycles over the 1024 resident slots (256 CUs x 4) against the launch duration (100 MHz-free estimate: the
+# shader clock is read from the longest-lived workgroup of an unloaded run; here the ratio to the measured launch is what matters)
+slots = 1024 if B >= 2304 else min(B, 512)
+clk = float(os.environ.get('UPH_CLK_MHZ', '2400')) * 1e3
+print('packing: sum(cycles)/slots = %.1f ms at %.0f MHz, longest workgroup %.1f ms, launch %.1f ms' % (tot / slots / clk, clk / 1e3, cy[:, 6].max() / clk, st['kernel_ms']))

@@ -20,6 +20,9 @@
 
 using namespace uph;
 
+#ifndef UPH_THOMAS_KPL
+#define UPH_THOMAS_KPL 4        // knots per lane of the knot solve: 64 lanes x 4 cover UPH_MAX_PIECE_YAW - 1 = 127 knots, 32 x 4 the 63 of an xy chain
+#endif
 #ifndef UPH_TWOLOOP_PF
 #define UPH_TWOLOOP_PF 5
 #endif
@@ -310,61 +313,107 @@ struct DevWG {
         const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
         return __hiloint2double(hi, lo);
     }
-    template <bool XY, bool ADJ>
+    // Blocked form: lane l owns the KPL consecutive knots KPL l + 1 .. KPL l + KPL.  With p the value handed over by the neighbour, every
+    // knot of the lane is affine in p, y_k = c_k + F_k p, with c_k = P_k r_k - M_k c_{k-1} and F_k = -M_k F_{k-1} (F_1 = -M_1) composed
+    // locally -- all lanes in parallel, no neighbour involved.  The serial part then carries ONLY the lane's last knot: one DPP shift
+    // and one 2x2 mat-vec per step, ceil(len / KPL) steps, instead of a shift and KPL dependent mat-vecs; the other knots follow from
+    // the final hand-over in parallel.  Same recurrence, other association of the products (differences at the 1e-16 level).
+    template <bool XY, bool ADJ, int KPL>
     __device__ __forceinline__ void thomasWave(const double* tab, double* buf, int len_) {
         const int len = uni(len_);
         const int lane = flane();
         const int hl = XY ? (lane & 31) : lane;
-        const int ja = 2 * hl + 1, jb = ja + 1;                 // knot ids, 1-based
-        const bool va = ja <= len, vb = jb <= len;
+        const int j0 = KPL * hl + 1;                            // the lane's first knot, 1-based
         constexpr int ks = XY ? 4 : 2, cs = XY ? 2 : 1;         // knot / component strides of the buffer
-        double* pa = buf + (size_t)(ja - 1) * ks + (XY ? (lane >> 5) : 0);
-        double* pb = pa + ks;
-        const double ra0 = va ? pa[0] : 0.0, ra1 = va ? pa[cs] : 0.0, rb0 = vb ? pb[0] : 0.0, rb1 = vb ? pb[cs] : 0.0;
-        double Pa[4], M1a[4], Qa[4], M2a[4], Pb[4], M1b[4], Qb[4], M2b[4];
-        thomasFactors<ADJ>(tab, va ? ja : 1, Pa, M1a, Qa, M2a);
-        thomasFactors<ADJ>(tab, vb ? jb : 1, Pb, M1b, Qb, M2b);
+        double* pk = buf + (size_t)(j0 - 1) * ks + (XY ? (lane >> 5) : 0);
+        double c[KPL][2], F[KPL][4], Qm[KPL][4], M2[KPL][4];
+        // ---- forward composition (ascending knots)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (!va) { Pa[k] = 0.0; M1a[k] = 0.0; Qa[k] = 0.0; M2a[k] = 0.0; }
-            if (!vb) { Pb[k] = 0.0; M1b[k] = 0.0; Qb[k] = 0.0; M2b[k] = 0.0; }
+        for (int k = 0; k < KPL; k++) {
+            const int j = j0 + k;
+            const bool v = j <= len;
+            const double r0 = v ? pk[k * ks] : 0.0, r1 = v ? pk[k * ks + cs] : 0.0;
+            double P[4], M1[4];
+            thomasFactors<ADJ>(tab, v ? j : 1, P, M1, Qm[k], M2[k]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { if (!v) { P[q] = 0.0; M1[q] = 0.0; Qm[k][q] = 0.0; M2[k][q] = 0.0; } }
+            double t0, t1;
+            mv2(P, r0, r1, t0, t1);
+            if (k == 0) {
+                c[0][0] = t0; c[0][1] = t1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) F[0][q] = -M1[q];
+            } else {
+                submv2(t0, t1, M1, c[k - 1][0], c[k - 1][1], c[k][0], c[k][1]);
+                F[k][0] = -fma(M1[1], F[k - 1][2], M1[0] * F[k - 1][0]); F[k][1] = -fma(M1[1], F[k - 1][3], M1[0] * F[k - 1][1]);
+                F[k][2] = -fma(M1[3], F[k - 1][2], M1[2] * F[k - 1][0]); F[k][3] = -fma(M1[3], F[k - 1][3], M1[2] * F[k - 1][1]);
+            }
         }
-        double Pa0, Pa1, Pb0, Pb1;
-        mv2(Pa, ra0, ra1, Pa0, Pa1);
-        mv2(Pb, rb0, rb1, Pb0, Pb1);
-        const int steps = (len + 1) >> 1;
-        double ya0 = 0.0, ya1 = 0.0, yb0 = 0.0, yb1 = 0.0;
+        const int steps = (len + KPL - 1) / KPL;
+        double y0 = 0.0, y1 = 0.0;
         for (int s = 0; s < steps; s++) {
-            const double p0 = shr1(yb0), p1 = shr1(yb1);
-            submv2(Pa0, Pa1, M1a, p0, p1, ya0, ya1);
-            submv2(Pb0, Pb1, M1b, ya0, ya1, yb0, yb1);
+            const double p0 = shr1(y0), p1 = shr1(y1);
+            y0 = fma(F[KPL - 1][1], p1, fma(F[KPL - 1][0], p0, c[KPL - 1][0]));
+            y1 = fma(F[KPL - 1][3], p1, fma(F[KPL - 1][2], p0, c[KPL - 1][1]));
         }
-        double qa0, qa1, qb0, qb1;
-        mv2(Qa, ya0, ya1, qa0, qa1);
-        mv2(Qb, yb0, yb1, qb0, qb1);
-        double za0 = 0.0, za1 = 0.0, zb0 = 0.0, zb1 = 0.0;
+        double yk[KPL][2];
+        {
+            const double p0 = shr1(y0), p1 = shr1(y1);
+#pragma unroll
+            for (int k = 0; k < KPL; k++) {
+                yk[k][0] = fma(F[k][1], p1, fma(F[k][0], p0, c[k][0]));
+                yk[k][1] = fma(F[k][3], p1, fma(F[k][2], p0, c[k][1]));
+            }
+        }
+        // ---- backward composition (descending knots): z_k = q_k - M2_k z_{k+1}, the lane's FIRST knot is handed to the left
+#pragma unroll
+        for (int k = KPL - 1; k >= 0; k--) {
+            double t0, t1;
+            mv2(Qm[k], yk[k][0], yk[k][1], t0, t1);
+            if (k == KPL - 1) {
+                c[k][0] = t0; c[k][1] = t1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) F[k][q] = -M2[k][q];
+            } else {
+                submv2(t0, t1, M2[k], c[k + 1][0], c[k + 1][1], c[k][0], c[k][1]);
+                F[k][0] = -fma(M2[k][1], F[k + 1][2], M2[k][0] * F[k + 1][0]); F[k][1] = -fma(M2[k][1], F[k + 1][3], M2[k][0] * F[k + 1][1]);
+                F[k][2] = -fma(M2[k][3], F[k + 1][2], M2[k][2] * F[k + 1][0]); F[k][3] = -fma(M2[k][3], F[k + 1][3], M2[k][2] * F[k + 1][1]);
+            }
+        }
+        double z0 = 0.0, z1 = 0.0;
         for (int s = 0; s < steps; s++) {
-            const double p0 = shl1(za0), p1 = shl1(za1);
-            submv2(qb0, qb1, M2b, p0, p1, zb0, zb1);
-            submv2(qa0, qa1, M2a, zb0, zb1, za0, za1);
+            const double p0 = shl1(z0), p1 = shl1(z1);
+            z0 = fma(F[0][1], p1, fma(F[0][0], p0, c[0][0]));
+            z1 = fma(F[0][3], p1, fma(F[0][2], p0, c[0][1]));
         }
-        if (va) { pa[0] = za0; pa[cs] = za1; }
-        if (vb) { pb[0] = zb0; pb[cs] = zb1; }
+        {
+            const double p0 = shl1(z0), p1 = shl1(z1);
+#pragma unroll
+            for (int k = 0; k < KPL; k++) {
+                if (j0 + k <= len) {
+                    pk[k * ks] = fma(F[k][1], p1, fma(F[k][0], p0, c[k][0]));
+                    pk[k * ks + cs] = fma(F[k][3], p1, fma(F[k][2], p0, c[k][1]));
+                }
+            }
+        }
     }
     template <bool ADJ>
     __device__ __forceinline__ void thomasT(const double* tab, double* bw, int lenW, double* bx, int lenX) {
         __builtin_amdgcn_s_setprio(3);              // dependency chains: let them win the issue arbitration
         if (NW >= 2) {
-            if (wave == 0) thomasWave<false, ADJ>(tab, bw, lenW);
-            else if (wave == 1) thomasWave<true, ADJ>(tab, bx, lenX);
+            if (wave == 0) thomasWave<false, ADJ, UPH_THOMAS_KPL>(tab, bw, lenW);
+            else if (wave == 1) thomasWave<true, ADJ, UPH_THOMAS_KPL>(tab, bx, lenX);
         } else {
-            thomasWave<false, ADJ>(tab, bw, lenW);
-            thomasWave<true, ADJ>(tab, bx, lenX);
+            thomasWave<false, ADJ, UPH_THOMAS_KPL>(tab, bw, lenW);
+            thomasWave<true, ADJ, UPH_THOMAS_KPL>(tab, bx, lenX);
         }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
     __device__ __forceinline__ void thomas(const double* tab, bool adj, double* bw, int lenW, double* bx, int lenX) {
+#ifdef UPH_NO_THOMAS       // timing experiment only (wrong results): what the knot solves cost under load
+        sync(); return;
+#endif
         if (adj) thomasT<true>(tab, bw, lenW, bx, lenX);
         else thomasT<false>(tab, bw, lenW, bx, lenX);
     }
