@@ -21,6 +21,7 @@ struct HostWG {
     void pfor(int n, F f) { for (int i = 0; i < n; i++) f(i); }
     void sync() {}
     long long clock() { return 0; }
+    long long realtime() { return 0; }
     template <class F>
     void one(F f) { f(); }
     template <int M, class F>

@@ -17,8 +17,18 @@ print('max total cycles', cy[:, 6].max(), ' => clock MHz ~', cy[:, 6].max() / (s
 for k, nme in enumerate(names[:6]):
     print('%-28s %5.1f %%   cycles/eval %9.0f' % (nme, 100 * cy[:, k].sum() / tot, cy[:, k].sum() / st['evals']))
 print('eval end -> twoloop start cycles/eval %9.0f' % (cy[:, 7].sum() / st['evals']))
-# packing: sum of workgroup cycles over the 1024 resident slots (256 CUs x 4) against the launch duration (100 MHz-free estimate: the
-# shader clock is read from the longest-lived workgroup of an unloaded run; here the ratio to the measured launch is what matters)
-slots = 1024 if B >= 2304 else min(B, 512)
-clk = float(os.environ.get('UPH_CLK_MHZ', '2400')) * 1e3
-print('packing: sum(cycles)/slots = %.1f ms at %.0f MHz, longest workgroup %.1f ms, launch %.1f ms' % (tot / slots / clk, clk / 1e3, cy[:, 6].max() / clk, st['kernel_ms']))
+# residency timeline from the 100 MHz start / end stamps of every workgroup: effective shader clock, and how long the launch runs
+# below full residency (the tail)
+t0, t1 = cy[:, 14], cy[:, 15]
+ok = t1 > t0
+if ok.any():
+    wall = (t1[ok] - t0[ok]) / 100e6
+    print('effective shader clock %.0f MHz (median over workgroups)' % np.median(cy[ok, 6] / wall / 1e6))
+    span = (t1[ok].max() - t0[ok].min()) / 100e6
+    ev = np.concatenate([np.stack([t0[ok], np.ones(ok.sum())], 1), np.stack([t1[ok], -np.ones(ok.sum())], 1)])
+    ev = ev[np.argsort(ev[:, 0], kind='stable')]
+    res = np.cumsum(ev[:, 1]); dt = np.diff(ev[:, 0]) / 100e6
+    full = res[:-1].max()
+    busy = (res[:-1] * dt).sum() / full
+    print('launch span %.1f ms, peak residency %d workgroups, residency-weighted time %.1f ms (= %.1f %% of the span), time below 90 %% residency %.1f ms'
+          % (span * 1e3, full, busy * 1e3, 100 * busy / span, dt[res[:-1] < 0.9 * full].sum() * 1e3))

@@ -1171,6 +1171,7 @@ struct Solver {
         scale_fx = wg.bcast(st.scale_fx);
         wg.pfor(n, [&](int t) { x[t] = gx0[t]; });
         const long long tstart = wg.clock();
+        cyc[14] = wg.realtime();                                         // residency timeline of the launch (tools/phase_breakdown.py): 100 MHz stamps
         int ret_code = 0, iter = 0, total_k = 0, last_ret = 0;
         double inner_cost = 0.0;
         while (true) {                                                    // :234-271
@@ -1190,6 +1191,7 @@ struct Solver {
         }
         wg.pfor(n, [&](int t) { gx0[t] = x[t]; bd.gout[td.off_x + t] = g[t]; });
         cyc[6] = wg.clock() - tstart;
+        cyc[15] = wg.realtime();
         storeTrajectory(st);
         wg.pfor(1, [&](int) {
             st.ret_code = ret_code; st.alm_iters = iter; st.lbfgs_iters = total_k; st.last_lbfgs_ret = last_ret; st.f = inner_cost;

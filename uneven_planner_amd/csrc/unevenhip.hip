@@ -106,6 +106,7 @@ struct DevWG {
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ int size() const { return NT; }
     __device__ __forceinline__ long long clock() { return (long long)__builtin_readcyclecounter(); }
+    __device__ __forceinline__ long long realtime() { return (long long)__builtin_amdgcn_s_memrealtime(); }      // constant 100 MHz
     template <class F>
     __device__ __forceinline__ void one(F f) { if (tid == 0) f(); }
 
