@@ -5,7 +5,9 @@ step      = one pass of the hot path over one batch: uph_batch_solve, i.e. B ful
             (initScaling + all ALM passes + all L-BFGS iterations) by one kernel launch, inputs resident in HBM.
 workload  = hill scene (synthetic hill cloud; map built by the device plane-fit kernel before the timed
             region, x-slab sharded + all-gathered over RCCL when N > 1), B start/goal problems per GPU drawn with the
-            config-3 protocol (seeds 1000 + rank*B + i, 3-10 m apart), parameters of run_hill.yaml.  Weak scaling: B per GPU fixed.
+            config-3 protocol (seeds 1000 + rank*B + i, 3-10 m apart), parameters of run_hill.yaml.  Weak scaling: B per GPU fixed
+            (default 16384: the tail of a launch -- workgroups finishing below full residency -- costs 18 % at 8192 and 8 % at 16384;
+            the line also carries B = 256 / 4096 / 8192).  --workload km2: BASELINE.json configs[4] (analytic 1 km^2 terrain, fp32 cells).
 value     = (B * n_gpus * K) / max-over-ranks wall time of K steps.
 roofline  = dominant kernel uph_solver_kernel: algorithmic bytes of one launch / its HIP-event duration, against 8 TB/s HBM.
 cpu_baseline = the CPU oracle (single thread, kind "port") on a bounded sample of the same batch, rank 0, N = 1 only.
