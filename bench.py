@@ -252,9 +252,17 @@ def main():
                 mdt = time.perf_counter() - t0
                 res["cpu_baseline_all_threads"] = {"value": nmt / mdt, "unit": "traj-opts/s", "cores": args.cpu_threads, "kind": "port",
                                                    "sample": "first %d problems, one trajectory per thread, %.1f s" % (nmt, mdt)}
-        print(json.dumps(res))
     if distributed:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL leaves its version banner in the C stdio buffer, which would otherwise be flushed at exit, after the line below
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
