@@ -14,6 +14,7 @@ cpu_baseline = the CPU oracle (single thread, kind "port") on a bounded sample o
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -60,6 +61,8 @@ def main():
                     help="hill: the BASELINE metric's scene (default).  km2: configs[4] -- analytic 1 km^2 fractal terrain in fp32 cells, --batch (default 4096) "
                          "local-goal solves in total, split over the ranks (strong scaling)")
     ap.add_argument("--map-size", type=float, default=1000.0, help="km2 workload: side of the square map [m]")
+    ap.add_argument("--tiled", action="store_true", help="km2 workload, N > 1: every rank holds only its x-slab of the grid plus a 20 m halo and solves the problems that "
+                                                         "start in its slab (owner routing, SURVEY.md 8e row 3) instead of replicating the grid")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = automatic: 128 for large batches)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="also time the CPU oracle with this many threads (one trajectory per thread; context only)")
     args = ap.parse_args()
@@ -87,13 +90,10 @@ def main():
     gather = lambda full, slab: dist.all_gather_into_tensor(full, slab)
     t0 = time.time()
     if km2:
-        # configs[4]: analytic fractal terrain, fp32 cells (16 bytes per cell; 1 km^2 at 0.25 m x 64 yaw bins = 16.4 GB, replicated per GPU)
-        from uneven_planner_amd.uneven_map import KM2_MAP_PARAMS
-        m = U.UnevenMap(dict(KM2_MAP_PARAMS, map_size_x=args.map_size, map_size_y=args.map_size), device=device, storage="f32")
-        if distributed:
-            m.fill_fbm_sharded(None, rank, world, gather)
-        else:
-            m.fill_fbm()
+        # configs[4]: analytic fractal terrain, fp32 cells (16 bytes per cell; 1 km^2 at 0.25 m x 64 yaw bins = 16.4 GB, replicated per GPU,
+        # or -- with --tiled -- one x-slab plus halo per GPU)
+        from uneven_planner_amd.uneven_map import km2_map
+        m = km2_map(args.map_size, rank, world, device, tiled=args.tiled, all_gather=gather if distributed else None)
     else:
         xyz = scenes.make_hill_cloud()      # hill cloud -> SE(2) grid by the plane-fit kernel
         m = U.UnevenMap(device=device)
@@ -112,7 +112,8 @@ def main():
         lo, args.batch = scenes.batch_share(total_batch, rank, world)      # this rank's share of the one batch (strong scaling)
         if args.batch < 1:
             raise SystemExit("km2: batch of %d cannot be split over %d ranks" % (total_batch, world))
-        probs = scenes.local_problems(args.batch, seed0=5000 + lo, half=0.5 * args.map_size - 5.0, occ_r2=m.occ_r2_buffer, grid=gridinfo)
+        from uneven_planner_amd.uneven_map import km2_problems
+        probs = km2_problems(m, args.map_size, args.batch, lo, rank, world)
     else:
         probs = scenes.random_problems(args.batch, seed0=1000 + rank * args.batch, occ_r2=m.occ_r2_buffer, grid=gridinfo)
     opt = U.ALMTrajOpt(m)
@@ -212,7 +213,7 @@ def main():
                                     "local-goal (4-14 m) full ALM solves split over the GPUs, run_hill.yaml params" % (args.map_size, args.map_size, total_batch)) if km2 else
                                    ("hill scene (synthetic hill cloud, map built on device), batch of %d random start/goal "
                                     "full ALM solves per GPU (configs[1] scene, configs[2] start/goal protocol), run_hill.yaml params" % args.batch),
-                       "batch_per_gpu": args.batch, "grid": [nx, ny, int(m.voxel_num[2])], "parallelism": "dp%d" % world},
+                       "batch_per_gpu": args.batch, "grid": [nx, ny, int(m.voxel_num[2])], "parallelism": ("dp%d" % world) + (" (grid tiled by x-slab owner + 20 m halo)" if km2 and m.tile is not None else "")},
             "ms_per_lbfgs_iter": single_ms_per_iter,       # single hill trajectory alone on the GPU (configs[1]): solve kernel ms / its L-BFGS iterations
             "single_traj_ms": single_ms, "batch_lbfgs_iters_per_s": iters / dt,
             "lbfgs_iters_per_traj": iters / K / args.batch, "evals_per_traj": evals / K / args.batch,

@@ -164,6 +164,7 @@ void* emu_create(const double* mp11, const double* cells4, const double* op21) {
     finishGrid(g);
     g.nx = (int)std::ceil(size[0] / g.xy_res); g.ny = (int)std::ceil(size[1] / g.xy_res); g.nyaw = (int)std::ceil(size[2] / g.yaw_res);
     g.gravity = mp11[10];
+    g.x_off = 0; g.nx_hold = g.nx;
     size_t nc = (size_t)g.nx * g.ny * g.nyaw;
     e->cells.assign(cells4, cells4 + 4 * nc);
     g.cells = e->cells.data(); g.cells32 = nullptr;

@@ -140,3 +140,26 @@ def test_map_csv_cross_reads_and_binary_sidecar(tmp_path, oracle):
     import pytest
     with pytest.raises(ValueError):
         HostGridView.read_map_binary(p3, 2.0, 1.0)
+
+
+def test_tile_rows_and_owner_routing_cover_every_problem():
+    """SURVEY.md 8e row 3, host side: x-slab tiles with a halo and the owner rule -- every problem has exactly one owner and lies inside
+    the owner's tile with room to spare when the halo exceeds the longest local goal"""
+    from uneven_planner_amd import scenes
+    from uneven_planner_amd.uneven_map import owner_of, route_problems, slab_bounds, tile_rows
+    nx, res, ox = 4000, 0.25, -500.0
+    probs = scenes.local_problems(200, seed0=5000, half=495.0)
+    for world in (1, 3, 8):
+        routes = route_problems(probs, nx, world, res, ox)
+        assert sorted(i for r in routes for i in r) == list(range(len(probs)))
+        halo = int(round(20.0 / res))
+        for rank, idx in enumerate(routes):
+            x0, x1 = tile_rows(nx, rank, world, halo)
+            _, a, b = slab_bounds(nx, rank, world)
+            assert 0 <= x0 <= a < b <= x1 <= nx
+            lo_m, hi_m = ox + x0 * res, ox + x1 * res
+            for i in idx:
+                p = probs[i]
+                xs = np.concatenate([p["init_xy"][0, :1], p["end_xy"][0, :1], p["inner_xy"][0]])
+                assert owner_of(p, nx, world, res, ox) == rank
+                assert (xs.min() >= lo_m + 2.0 or x0 == 0) and (xs.max() <= hi_m - 2.0 or x1 == nx)      # UPH_TILE_MARGIN of the upload check

@@ -65,6 +65,8 @@ SYMBOLS = {
     "uph_map_create": (C.c_int, [C.POINTER(MapParams), C.c_int, C.POINTER(_VP)]),
     "uph_map_create_f32": (C.c_int, [C.POINTER(MapParams), C.c_int, C.POINTER(_VP)]),
     "uph_map_storage_bytes": (C.c_int, [_VP]),
+    "uph_map_create_tile": (C.c_int, [C.POINTER(MapParams), C.c_int, _I32, _I32, _I32, C.POINTER(_VP)]),
+    "uph_map_tile": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
     "uph_map_fill_fbm": (C.c_int, [_VP, C.POINTER(FbmParams), _I32, _I32]),
     "uph_fbm_table": (C.c_int, [C.POINTER(FbmParams), DP]),
     "uph_map_get_window": (C.c_int, [_VP, _I32, _I32, _I32, _I32, DP]),

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void uph_map_build_kernel(GridDev g, CloudDev c
     const double einv0 = 1.0 / ell_x, einv1 = 1.0 / ell_y, einv2 = 1.0 / ell_z;
     const float r2f = (float)box_r * (float)box_r;
     for (int yaw = lane; yaw < g.nyaw; yaw += 64) {
-        const size_t addr = ((size_t)x * g.ny + y) * g.nyaw + yaw;
+        const size_t addr = ((size_t)(x - g.x_off) * g.ny + y) * g.nyaw + yaw;
         // constructMap starts every cell from a fresh RXS2() with c_buffer = 1 (uneven_map.cpp:117-119, 329-331), whatever an earlier
         // build, set_cells or import left in the slab
         double cz = 0.0, csig = 0.0, czbx = 0.0, czby = 0.0, cc = 1.0;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64) void uph_map_fbm_kernel(GridDev g, FbmDev f, Ce
     const double ccx = (x + 0.5) * g.xy_res + g.origin[0];           // indexToPos, uneven_map.h:419-425
     const double ccy = (y + 0.5) * g.xy_res + g.origin[1];
     for (int yaw = threadIdx.x; yaw < g.nyaw; yaw += 64) {
-        const size_t addr = ((size_t)x * g.ny + y) * g.nyaw + yaw;
+        const size_t addr = ((size_t)(x - g.x_off) * g.ny + y) * g.nyaw + yaw;
         double cz = 0.0, csig = 0.0, czbx = 0.0, czby = 0.0, cc = 1.0;      // fresh RXS2(), c = 1 (uneven_map.cpp:117-119)
         const double yawc = (yaw + 0.5) * g.yaw_res + g.origin[2];
         const double cyw = cos(yawc), syw = sin(yawc);
@@ -445,8 +445,8 @@ HostCloud cropAndVoxel(const float* xyz, int64_t n) {
 
 int commitMap(uph_map* m) {
     const GridDev& g = m->g;
-    const int ncol = g.nx * g.ny;
-    hipLaunchKernelGGL(uph_map_commit_kernel, dim3((ncol + 255) / 256), dim3(256), 0, 0, g.nx, g.ny, g.nyaw, m->d_cells, m->d_cells32, m->d_c, m->d_occ,
+    const int ncol = g.nx_hold * g.ny;
+    hipLaunchKernelGGL(uph_map_commit_kernel, dim3((ncol + 255) / 256), dim3(256), 0, 0, g.nx_hold, g.ny, g.nyaw, m->d_cells, m->d_cells32, m->d_c, m->d_occ,
                        m->d_occ2, m->mp.min_cnormal, m->mp.max_rho);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -468,9 +468,10 @@ __global__ void uph_frontend_kernel(GridDev g, const char* __restrict__ occ, con
     terrainValues(g, c, tv);
     sigma[i] = tv[0];
     const int ix = (int)floor((x - g.origin[0]) * g.xy_inv), iy = (int)floor((y - g.origin[1]) * g.xy_inv), iw = (int)floor((w - g.origin[2]) * g.yaw_inv);
-    const bool in = ix >= 0 && iy >= 0 && iw >= 0 && ix <= g.nx - 1 && iy <= g.ny - 1 && iw <= g.nyaw - 1;
-    occ_out[i] = in ? (int)occ[((size_t)ix * g.ny + iy) * g.nyaw + iw] : -1;
-    occxy_out[i] = in ? (int)occ2[(size_t)ix * g.ny + iy] : -1;
+    const int ixh = ix - g.x_off;           // (a tile answers -1 outside the rows it holds)
+    const bool in = ix >= 0 && iy >= 0 && iw >= 0 && ix <= g.nx - 1 && iy <= g.ny - 1 && iw <= g.nyaw - 1 && ixh >= 0 && ixh <= g.nx_hold - 1;
+    occ_out[i] = in ? (int)occ[((size_t)ixh * g.ny + iy) * g.nyaw + iw] : -1;
+    occxy_out[i] = in ? (int)occ2[(size_t)ixh * g.ny + iy] : -1;
 }
 
 // UnevenMap::getTerrainPos (uneven_map.h:203-218): SE(3) pose on the terrain, one query per lane.  out[12] = R column-major
@@ -497,7 +498,7 @@ __global__ void uph_pose_kernel(GridDev g, const double* __restrict__ pos, int n
 
 extern "C" {
 
-static int createMap(const uph_map_params* mp, int device, uph_map** out, bool f32) {
+static int createMap(const uph_map_params* mp, int device, uph_map** out, bool f32, int tx0 = 0, int tx1 = -1) {
     if (!mp || !out) { setError("uph_map_create: null argument"); return UPH_ERR_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { setError("uph_map_create: no HIP device visible"); return UPH_ERR_NO_DEVICE; }
@@ -515,7 +516,10 @@ static int createMap(const uph_map_params* mp, int device, uph_map** out, bool f
     finishGrid(g);
     g.nx = (int)std::ceil(size[0] / g.xy_res); g.ny = (int)std::ceil(size[1] / g.xy_res); g.nyaw = (int)std::ceil(size[2] / g.yaw_res);   // :108-110
     g.gravity = mp->gravity;
-    m->ncell = (size_t)g.nx * g.ny * g.nyaw;
+    if (tx1 < 0) tx1 = g.nx;
+    if (tx0 < 0 || tx1 > g.nx || tx0 >= tx1) { delete m; setError("uph_map_create_tile: bad x-range"); return UPH_ERR_INVALID; }
+    g.x_off = tx0; g.nx_hold = tx1 - tx0;
+    m->ncell = (size_t)g.nx_hold * g.ny * g.nyaw;
     g.cells = nullptr; g.cells32 = nullptr;
     int r = UPH_OK;
     auto alloc = [&](void** p, size_t bytes) { if (r == UPH_OK && hipMalloc(p, bytes) != hipSuccess) { setError("uph_map_create: hipMalloc of the grid failed"); r = UPH_ERR_HIP; } };
@@ -530,7 +534,7 @@ static int createMap(const uph_map_params* mp, int device, uph_map** out, bool f
         g.cells = m->d_cells;
     }
     alloc((void**)&m->d_occ, m->ncell);
-    alloc((void**)&m->d_occ2, (size_t)g.nx * g.ny);
+    alloc((void**)&m->d_occ2, (size_t)g.nx_hold * g.ny);
     if (r == UPH_OK) r = commitMap(m);
     if (r != UPH_OK) { uph_map_destroy(m); return r; }
     *out = m;
@@ -539,6 +543,12 @@ static int createMap(const uph_map_params* mp, int device, uph_map** out, bool f
 
 int uph_map_create(const uph_map_params* mp, int device, uph_map** out) { return createMap(mp, device, out, false); }
 int uph_map_create_f32(const uph_map_params* mp, int device, uph_map** out) { return createMap(mp, device, out, true); }
+int uph_map_create_tile(const uph_map_params* mp, int device, int32_t x0, int32_t x1, int32_t f32, uph_map** out) { return createMap(mp, device, out, f32 != 0, x0, x1); }
+int uph_map_tile(const uph_map* m, int32_t* x0, int32_t* x1) {
+    if (!m || !x0 || !x1) return UPH_ERR_INVALID;
+    *x0 = m->g.x_off; *x1 = m->g.x_off + m->g.nx_hold;
+    return UPH_OK;
+}
 int uph_map_storage_bytes(const uph_map* m) { return !m ? UPH_ERR_INVALID : (m->d_cells32 ? 4 : 8); }
 
 void uph_map_destroy(uph_map* m) {
@@ -592,17 +602,17 @@ int uph_map_get_cells(uph_map* m, double* rxs2, double* c, char* occ, char* occ_
     }
     if (c) HIPCHK(hipMemcpy(c, m->d_c, m->ncell * sizeof(double), hipMemcpyDeviceToHost));
     if (occ) HIPCHK(hipMemcpy(occ, m->d_occ, m->ncell, hipMemcpyDeviceToHost));
-    if (occ_r2) HIPCHK(hipMemcpy(occ_r2, m->d_occ2, (size_t)m->g.nx * m->g.ny, hipMemcpyDeviceToHost));
+    if (occ_r2) HIPCHK(hipMemcpy(occ_r2, m->d_occ2, (size_t)m->g.nx_hold * m->g.ny, hipMemcpyDeviceToHost));
     return UPH_OK;
 }
 
 int uph_map_get_window(uph_map* m, int32_t x0, int32_t x1, int32_t y0, int32_t y1, double* rxs2) {
-    if (!m || !rxs2 || x0 < 0 || y0 < 0 || x1 > m->g.nx || y1 > m->g.ny || x0 >= x1 || y0 >= y1) { setError("uph_map_get_window: bad arguments"); return UPH_ERR_INVALID; }
+    if (!m || !rxs2 || x0 < m->g.x_off || y0 < 0 || x1 > m->g.x_off + m->g.nx_hold || y1 > m->g.ny || x0 >= x1 || y0 >= y1) { setError("uph_map_get_window: bad arguments (x is a global row index inside the held rows)"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
     const size_t n = (size_t)(x1 - x0) * (y1 - y0) * m->g.nyaw * 4;
     UphDevTmp t;
     HIPCHK(hipMalloc(&t.p, n * sizeof(double)));
-    hipLaunchKernelGGL(uph_window_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, m->g.ny, m->g.nyaw, m->d_cells, m->d_cells32, x0, y0, x1 - x0, y1 - y0, t.as<double>());
+    hipLaunchKernelGGL(uph_window_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, m->g.ny, m->g.nyaw, m->d_cells, m->d_cells32, x0 - m->g.x_off, y0, x1 - x0, y1 - y0, t.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(rxs2, t.p, n * sizeof(double), hipMemcpyDeviceToHost));
     return UPH_OK;
@@ -621,10 +631,10 @@ int uph_map_cells_device(uph_map* m, void** dptr, int64_t* nbytes) {
 // device-to-device slab traffic for the sharded build: export this rank's x-slab into a caller buffer (e.g. a torch tensor
 // that RCCL all-gathers), import the gathered full cell array.  Element type = the map's storage (double, or float in fp32 mode)
 int uph_map_export_slab_dev(uph_map* m, int32_t x0, int32_t x1, void* dst_dev) {
-    if (!m || !dst_dev || x0 < 0 || x1 > m->g.nx || x0 >= x1) { setError("uph_map_export_slab_dev: bad arguments"); return UPH_ERR_INVALID; }
+    if (!m || !dst_dev || x0 < m->g.x_off || x1 > m->g.x_off + m->g.nx_hold || x0 >= x1) { setError("uph_map_export_slab_dev: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
     const size_t per_x = (size_t)m->g.ny * m->g.nyaw * cellBytes(m);
-    HIPCHK(hipMemcpy(dst_dev, cellBase(m) + (size_t)x0 * per_x, (size_t)(x1 - x0) * per_x, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(dst_dev, cellBase(m) + (size_t)(x0 - m->g.x_off) * per_x, (size_t)(x1 - x0) * per_x, hipMemcpyDeviceToDevice));
     return UPH_OK;
 }
 int uph_map_import_cells_dev(uph_map* m, const void* src_dev) {
@@ -696,8 +706,8 @@ int uph_fbm_table(const uph_fbm_params* fp, double* table) {
 
 int uph_map_fill_fbm(uph_map* m, const uph_fbm_params* fp, int32_t x0, int32_t x1) {
     if (!m || !checkFbm(fp)) { setError("uph_map_fill_fbm: bad arguments"); return UPH_ERR_INVALID; }
-    if (x1 <= 0) x1 = m->g.nx;
-    if (x0 < 0 || x1 > m->g.nx || x0 >= x1) { setError("uph_map_fill_fbm: bad slab"); return UPH_ERR_INVALID; }
+    if (x1 <= 0) { x0 = m->g.x_off; x1 = m->g.x_off + m->g.nx_hold; }
+    if (x0 < m->g.x_off || x1 > m->g.x_off + m->g.nx_hold || x0 >= x1) { setError("uph_map_fill_fbm: slab outside the rows this map holds"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
     FbmDev f;
     buildFbm(*fp, f);
@@ -731,7 +741,7 @@ int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x
     if (m && m->d_cells32) { setError("uph_map_build: the plane fit writes fp64 cells; create the map with uph_map_create"); return UPH_ERR_INVALID; }
     if (!m || !xyz || n <= 0) { setError("uph_map_build: bad arguments"); return UPH_ERR_INVALID; }
     const GridDev& g = m->g;
-    if (x0 < 0 || x1 > g.nx || x0 >= x1) { setError("uph_map_build: bad x-slab"); return UPH_ERR_INVALID; }
+    if (x0 < g.x_off || x1 > g.x_off + g.nx_hold || x0 >= x1) { setError("uph_map_build: bad x-slab"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
     HostCloud cl = cropAndVoxel(xyz, n);
     const size_t np = cl.size();

@@ -57,10 +57,16 @@ UPH_HD void locate(const GridDev& g, double x, double y, double yaw, Corners& c)
         w1 = w1 > g.nyaw - 1 ? w1 - g.nyaw : (w1 < 0 ? w1 + g.nyaw : w1);
     }
     c.w0 = w0; c.w1 = w1;
-    c.a[0][0] = ((int64_t)x0 * g.ny + y0) * g.nyaw;
-    c.a[0][1] = ((int64_t)x0 * g.ny + y1) * g.nyaw;
-    c.a[1][0] = ((int64_t)x1 * g.ny + y0) * g.nyaw;
-    c.a[1][1] = ((int64_t)x1 * g.ny + y1) * g.nyaw;
+    // rows relative to the held part of the grid (a tile holds the x-rows [x_off, x_off + nx_hold) of the global grid: same index
+    // arithmetic as the whole grid, so a lookup inside the tile is bit-identical).  Rows outside are clamped to the tile -- memory
+    // safe; the host keeps trajectories inside their tile (uph_batch_upload / download checks).
+    int xa = x0 - g.x_off, xb = x1 - g.x_off;
+    xa = xa < 0 ? 0 : (xa > g.nx_hold - 1 ? g.nx_hold - 1 : xa);
+    xb = xb < 0 ? 0 : (xb > g.nx_hold - 1 ? g.nx_hold - 1 : xb);
+    c.a[0][0] = ((int64_t)xa * g.ny + y0) * g.nyaw;
+    c.a[0][1] = ((int64_t)xa * g.ny + y1) * g.nyaw;
+    c.a[1][0] = ((int64_t)xb * g.ny + y0) * g.nyaw;
+    c.a[1][1] = ((int64_t)xb * g.ny + y1) * g.nyaw;
 }
 
 // One cell of the grid: {z, sigma, zb.x, zb.y} in the reference's RXS2 order (uneven_map.h:36-64, 427-435), stored either as four

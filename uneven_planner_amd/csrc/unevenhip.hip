@@ -751,6 +751,9 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     placeholder.init_xy[2] = 0.05; placeholder.end_xy[0] = 0.6; placeholder.end_xy[2] = 0.05; placeholder.total_time = 1.44;
     std::vector<const uph_problem*> pp(B);
     c->rejected.assign(B, 0); c->n_rejected = 0;
+    const GridDev tg = uphMapGrid(c->map);
+    const bool tiled = tg.nx_hold < tg.nx;
+    const double tile_lo = tg.origin[0] + tg.x_off * tg.xy_res, tile_hi = tg.origin[0] + (tg.x_off + tg.nx_hold) * tg.xy_res;
     std::string why;
     for (int b = 0; b < B; b++) {
         const uph_problem& q = probs[b];
@@ -759,6 +762,11 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         if (q.n_inner_xy < 1 || q.n_inner_yaw < 1 || !q.inner_xy || !q.inner_yaw) { rj = UPH_ERR_INVALID; msg = "uph_batch_upload: a problem needs at least one inner way-point per block"; }
         else if (q.n_inner_xy + 1 > UPH_MAX_PIECE_XY || q.n_inner_yaw + 1 > UPH_MAX_PIECE_YAW) { rj = UPH_ERR_LIMIT; msg = "uph_batch_upload: piece count exceeds UPH_MAX_PIECE_*"; }
         else if (q.n_inner_yaw < q.n_inner_xy) { rj = UPH_ERR_INVALID; msg = "uph_batch_upload: piece_yaw < piece_xy (the reference indexes yaw_minco.T1 with the xy piece index, alm_traj_opt.cpp:749)"; }
+        else if (tiled) {                // a tile map serves the problems routed to it: the initial path must lie well inside the held rows (the grid's own border is no tile border)
+            double lo = std::min(q.init_xy[0], q.end_xy[0]), hi = std::max(q.init_xy[0], q.end_xy[0]);
+            for (int i = 0; i < q.n_inner_xy; i++) { lo = std::min(lo, q.inner_xy[2 * i]); hi = std::max(hi, q.inner_xy[2 * i]); }
+            if ((tg.x_off > 0 && lo < tile_lo + UPH_TILE_MARGIN) || (tg.x_off + tg.nx_hold < tg.nx && hi > tile_hi - UPH_TILE_MARGIN)) { rj = UPH_ERR_INVALID; msg = "uph_batch_upload: the path does not lie inside this map tile (route it to the tile's owner)"; }
+        }
         c->rejected[b] = rj;
         pp[b] = rj ? &placeholder : &q;
         if (rj) { if (!c->n_rejected) { why = msg; first_rj = rj; } c->n_rejected++; }
@@ -908,6 +916,9 @@ int uph_batch_download(uph_ctx* c, uph_result* results) {
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     int r = refreshStates(c);
     if (r != UPH_OK) return r;
+    const GridDev tg = uphMapGrid(c->map);
+    const bool tiled = tg.nx_hold < tg.nx;
+    const double tile_lo = tg.origin[0] + tg.x_off * tg.xy_res, tile_hi = tg.origin[0] + (tg.x_off + tg.nx_hold) * tg.xy_res;
     std::vector<double> x(c->sum_n), cxy(c->sum_cxy), cyaw(c->sum_cyaw), dual(7 * c->sum_S), res(7 * c->sum_S), scl(7 * c->sum_S);
     HIPCHK(hipMemcpy(x.data(), c->d_x.p, 8 * c->sum_n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(cxy.data(), c->d_cxy.p, 8 * c->sum_cxy, hipMemcpyDeviceToHost));
@@ -926,6 +937,11 @@ int uph_batch_download(uph_ctx* c, uph_result* results) {
         }
         o.ret_code = s.ret_code; o.alm_iters = s.alm_iters; o.lbfgs_iters = s.lbfgs_iters; o.evals = s.evals; o.last_lbfgs_ret = s.last_lbfgs_ret;
         o.cost = s.f; o.jerk_cost = s.jerk_cost; o.piece_T_xy = s.T_xy; o.piece_T_yaw = s.T_yaw; o.rho_final = s.rho; o.scale_fx = s.scale_fx;
+        if (tiled) {                     // lookups outside the held rows were clamped to the tile: such a result is not the whole grid's
+            const double* xf = x.data() + t.off_x;
+            for (int i = 0; i < t.Nxy - 1; i++)
+                if ((tg.x_off > 0 && xf[1 + 2 * i] < tile_lo + 2.0 * tg.xy_res) || (tg.x_off + tg.nx_hold < tg.nx && xf[1 + 2 * i] > tile_hi - 2.0 * tg.xy_res)) o.ret_code = UPH_RET_LEFT_TILE;
+        }
         if (o.x_final) std::memcpy(o.x_final, x.data() + t.off_x, 8 * t.n);
         if (o.c_xy) std::memcpy(o.c_xy, cxy.data() + t.off_cxy, 8 * 12 * t.Nxy);
         if (o.c_yaw) std::memcpy(o.c_yaw, cyaw.data() + t.off_cyaw, 8 * 6 * t.Nyaw);

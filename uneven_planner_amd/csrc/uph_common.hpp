@@ -65,7 +65,8 @@ enum {
 
 // Terrain grid in HBM: SoA planes, reference cell order (x slowest, yaw fastest; uneven_map.h:427-435)
 struct GridDev {
-    int nx, ny, nyaw;
+    int nx, ny, nyaw;             // dimensions of the WHOLE grid (index clamping, uneven_map.h:398-409)
+    int x_off, nx_hold;           // rows held in memory: global x index of the first one and their number (x_off = 0, nx_hold = nx unless the map is a tile)
     double xy_res, yaw_res, xy_inv, yaw_inv;
     double origin[3], minb[3], maxb[3];
     double lo[3], hi[3];          // minb + 1e-4, maxb - 1e-4 (isInMap), formed once on the host so that they stay scalar operands

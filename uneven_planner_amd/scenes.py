@@ -96,15 +96,16 @@ def batch_share(total, rank, world):
     return lo, min(per, total - lo)
 
 
-def local_problems(n, seed0=5000, half=495.0, dmin=4.0, dmax=14.0, occ_r2=None, grid=None, max_pieces=64, **mk):
+def local_problems(n, seed0=5000, half=495.0, dmin=4.0, dmax=14.0, occ_r2=None, grid=None, max_pieces=64, xlim=None, **mk):
     """SURVEY.md 8c row 5 (BASELINE.json configs[4]) protocol: one PCG64 stream per problem (seed0+i): start ~ U([-half,half]^2), goal at
     distance U[dmin,dmax] in a uniform direction, both yaws ~ U(-pi,pi); accepted when both cells are free, the goal is inside the
-    square and the resampled path has at most max_pieces position pieces (UPH_MAX_PIECE_XY)."""
+    square and the resampled path has at most max_pieces position pieces (UPH_MAX_PIECE_XY).  xlim = (lo, hi): starts drawn with x in
+    that interval (the x-slab of a tile owner)."""
     out = []
     for i in range(n):
         rng = np.random.Generator(np.random.PCG64(seed0 + i))
         while True:
-            s = np.array([rng.uniform(-half, half), rng.uniform(-half, half), rng.uniform(-math.pi, math.pi)])
+            s = np.array([rng.uniform(-half, half) if xlim is None else rng.uniform(xlim[0], xlim[1]), rng.uniform(-half, half), rng.uniform(-math.pi, math.pi)])
             d, th = rng.uniform(dmin, dmax), rng.uniform(-math.pi, math.pi)
             g = np.array([s[0] + d * math.cos(th), s[1] + d * math.sin(th), rng.uniform(-math.pi, math.pi)])
             if abs(g[0]) > half or abs(g[1]) > half:

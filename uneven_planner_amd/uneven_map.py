@@ -70,11 +70,68 @@ def gather_slabs(slab, nx, row_elems, world, all_gather):
     return full[:nx * row_elems]
 
 
+# ---- tiles: x-slab ownership with a halo -------------------------------------------------------------------------
+def tile_rows(nx, rank, world, halo_cells):
+    """rows [x0, x1) rank r holds: its x-slab (slab_bounds) widened by the halo, cut at the grid border"""
+    _, a, b = slab_bounds(nx, rank, world)
+    return max(0, a - int(halo_cells)), min(int(nx), b + int(halo_cells))
+
+
+def owner_of(prob, nx, world, xy_resolution, origin_x):
+    """the rank whose x-slab contains the midpoint of the problem's x-extent"""
+    xs = np.concatenate([np.asarray(prob["init_xy"])[0, :1], np.asarray(prob["end_xy"])[0, :1], np.asarray(prob["inner_xy"]).reshape(2, -1)[0]])
+    ix = int(math.floor((0.5 * (xs.min() + xs.max()) - origin_x) / xy_resolution))
+    per = -(-int(nx) // int(world))
+    return min(max(ix // per, 0), world - 1)
+
+
+def route_problems(probs, nx, world, xy_resolution, origin_x):
+    """host-side routing of a batch to tile owners: list (per rank) of the indices of the problems it solves"""
+    out = [[] for _ in range(world)]
+    for i, p in enumerate(probs):
+        out[owner_of(p, nx, world, xy_resolution, origin_x)].append(i)
+    return out
+
+
+def km2_map(map_size, rank=0, world=1, device=0, tiled=False, all_gather=None, halo_m=20.0):
+    """BASELINE.json configs[4] scene for one rank: analytic fractal terrain in fp32 cells.  Replicated grid (filled in x-slabs with one
+    all-gather when `all_gather` is given), or -- tiled, world > 1 -- only this rank's x-slab plus halo, filled locally (no exchange: the
+    surface is analytic)."""
+    kp = dict(KM2_MAP_PARAMS, map_size_x=float(map_size), map_size_y=float(map_size))
+    tile = None
+    if tiled and world > 1:
+        nx_all = int(math.ceil(float(map_size) / kp["xy_resolution"]))
+        tile = tile_rows(nx_all, rank, world, int(round(halo_m / kp["xy_resolution"])))
+    m = UnevenMap(kp, device=device, storage="f32", tile=tile)
+    if tile is None and all_gather is not None:
+        m.fill_fbm_sharded(None, rank, world, all_gather)
+    else:
+        m.fill_fbm()
+    return m
+
+
+def km2_problems(m, map_size, count, first_seed_offset, rank=0, world=1):
+    """`count` local-goal problems (seeds 5000 + first_seed_offset + i) on a km2_map; on a tile they start inside the rank's own x-slab --
+    owner routing by construction -- and occupancy is read from the held rows"""
+    from . import scenes
+    nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
+    half = 0.5 * float(map_size) - 5.0
+    grid, xlim = (nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]), None
+    if m.tile is not None:
+        _, sa, sb = slab_bounds(nx, rank, world)
+        xlim = (max(-half, m.map_origin[0] + sa * m.xy_resolution), min(half, m.map_origin[0] + sb * m.xy_resolution))
+        grid = (m.rows_held, ny, m.xy_resolution, m.map_origin[0] + m.tile[0] * m.xy_resolution, m.map_origin[1])
+    return scenes.local_problems(count, seed0=5000 + first_seed_offset, half=half, occ_r2=m.occ_r2_buffer, grid=grid, xlim=xlim)
+
+
 class UnevenMap:
-    def __init__(self, params=None, device=0, storage="f64"):
-        """storage "f64": cells as the reference's doubles; "f32": four floats per cell (configs[4]; lookups widen to double)"""
+    def __init__(self, params=None, device=0, storage="f64", tile=None):
+        """storage "f64": cells as the reference's doubles; "f32": four floats per cell (configs[4]; lookups widen to double).
+        tile = (x0, x1): hold only the x-rows [x0, x1) of the grid (uph_map_create_tile; grids that do not fit one GPU): voxel_num keeps
+        the whole grid's dimensions, the host buffers cover the held rows."""
         assert storage in ("f64", "f32")
         self.storage = storage
+        self.tile = None if tile is None else (int(tile[0]), int(tile[1]))
         self.L = _lib.load()
         _lib.require_device()
         q = dict(HILL_MAP_PARAMS)
@@ -83,8 +140,11 @@ class UnevenMap:
         self.params = q
         self._mp = _lib.MapParams(**{k: (int(v) if k == "iter_num" else float(v)) for k, v in q.items()})
         h = C.c_void_p()
-        create = self.L.uph_map_create if storage == "f64" else self.L.uph_map_create_f32
-        _lib.check(create(C.byref(self._mp), int(device), C.byref(h)), "uph_map_create")
+        if self.tile is not None:
+            _lib.check(self.L.uph_map_create_tile(C.byref(self._mp), int(device), self.tile[0], self.tile[1], int(storage == "f32"), C.byref(h)), "uph_map_create_tile")
+        else:
+            create = self.L.uph_map_create if storage == "f64" else self.L.uph_map_create_f32
+            _lib.check(create(C.byref(self._mp), int(device), C.byref(h)), "uph_map_create")
         self.h = h
         d = (C.c_int32 * 3)()
         _lib.check(self.L.uph_map_dims(self.h, d), "uph_map_dims")
@@ -93,7 +153,8 @@ class UnevenMap:
         self.map_size = np.array([q["map_size_x"], q["map_size_y"], 2.0 * math.pi + 5e-2])
         self.min_boundary, self.max_boundary = -self.map_size / 2.0, self.map_size / 2.0
         self.map_origin = self.min_boundary.copy()
-        self.ncell = int(np.prod(self.voxel_num))
+        self.rows_held = int(self.voxel_num[0]) if self.tile is None else self.tile[1] - self.tile[0]
+        self.ncell = self.rows_held * int(self.voxel_num[1]) * int(self.voxel_num[2])      # cells in memory
         self.map_ready = False
         self.map_buffer = self.c_buffer = self.occ_buffer = self.occ_r2_buffer = None
         self.device = device
@@ -163,8 +224,8 @@ class UnevenMap:
         return self
 
     def download(self):
-        occ2 = np.zeros(int(self.voxel_num[0] * self.voxel_num[1]), dtype=np.int8)
-        if self.ncell > DOWNLOAD_LIMIT_CELLS:         # km^2-scale grid: cells stay on the device (get_window serves pieces of it)
+        occ2 = np.zeros(self.rows_held * int(self.voxel_num[1]), dtype=np.int8)
+        if self.ncell > DOWNLOAD_LIMIT_CELLS or self.tile is not None:         # km^2-scale grid: cells stay on the device (get_window serves pieces of it)
             _lib.check(self.L.uph_map_get_cells(self.h, None, None, None, occ2.ctypes.data_as(C.c_char_p)), "uph_map_get_cells")
             self.map_buffer = self.c_buffer = self.occ_buffer = self.host = None
             self.occ_r2_buffer = occ2
@@ -190,7 +251,9 @@ class UnevenMap:
         """fill the x-slab [x0, x1) with the analytic fBm terrain (uph_map_fill_fbm): a constructMap-style plane fit per cell on samples of
         the analytic surface"""
         fp = _fbm(fbm)
-        _lib.check(self.L.uph_map_fill_fbm(self.h, C.byref(fp), int(x0), int(self.voxel_num[0]) if x1 is None else int(x1)), "uph_map_fill_fbm")
+        if x1 is None:
+            x0, x1 = (0, int(self.voxel_num[0])) if self.tile is None else self.tile
+        _lib.check(self.L.uph_map_fill_fbm(self.h, C.byref(fp), int(x0), int(x1)), "uph_map_fill_fbm")
         if download:
             self.download()
         self.map_ready = True
