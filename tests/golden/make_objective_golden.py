@@ -1,0 +1,218 @@
+"""Generates tests/golden/objective_golden.npz: the augmented-Lagrangian objective of the optimiser (innerCallback,
+back_end/src/alm_traj_opt.cpp:280-347, with calConstrainCostGrad :663-991) and its gradient from an INDEPENDENT model:
+
+  * forward values only, written here from the reference's formulas in vectorised torch float64 -- MINCO by a dense
+    torch.linalg.solve of the 6N x 6N system (se2traj.hpp:612-674), closed-form jerk integral, trilinear terrain lookup with the
+    reference's index arithmetic (uneven_map.h:268-311, 398-409), attitude terms (:327-348), PHR penalties (alm_traj_opt.h:154-163);
+  * the gradient by AUTOGRAD through all of it (MINCO solve, time map, lookup, penalties) -- no hand-derived adjoint, no
+    calGradCTtoQT, no calJerkGradCT;
+  * the one place where the reference's gradient is knowingly not the derivative of its cost (quirk Q3, `gdTxy(i) += user_cost /
+    int_K`, alm_traj_opt.cpp:827) is added to the tau entry explicitly.
+
+The reference ships no tests or vectors and cannot be built here, so this pins the oracle's objective and its whole hand-written
+gradient chain against a second, structurally different derivation ("parity unpinned" still holds).
+Run:  python tests/golden/make_objective_golden.py   (CPU, torch + numpy; deterministic)."""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+torch.set_default_dtype(torch.float64)
+
+# run_hill.yaml:32-55 and alm_traj_opt.h:16-19
+P = dict(rho_T=100000.0, rho_ter=10.0, max_vel=0.5, max_acc_lon=5.0, max_acc_lat=10.0, max_kap=2.1, min_cxi=0.8, max_sig=0.05, int_K=16,
+         gravity=9.81, delta_sigl=0.01, scale_trick_jerk=1000.0)
+GRID = dict(size_x=10.0, size_y=10.0, xy_res=0.05, yaw_res=0.1)
+
+
+def expC2(tau):
+    return torch.where(tau > 0, (0.5 * tau + 1.0) * tau + 1.0, 1.0 / ((0.5 * tau - 1.0) * tau + 1.0))
+
+
+def minco(q, T, head, tail):
+    """q (N-1, D), T scalar tensor (uniform piece time), head / tail (3, D) rows P, V, A -> coefficients (N, 6, D), ascending powers"""
+    N = q.shape[0] + 1
+    D = q.shape[1]
+    A = torch.zeros(6 * N, 6 * N)
+    b = torch.zeros(6 * N, D)
+    A[0, 0] = 1.0; A[1, 1] = 1.0; A[2, 2] = 2.0
+    b[0:3] = head
+    t = T
+    pw = [t ** k for k in range(6)]
+    for i in range(N - 1):
+        r = 6 * i
+        A[r + 3, r + 3] = 6.0; A[r + 3, r + 4] = 24.0 * pw[1]; A[r + 3, r + 5] = 60.0 * pw[2]; A[r + 3, r + 9] = -6.0
+        A[r + 4, r + 4] = 24.0; A[r + 4, r + 5] = 120.0 * pw[1]; A[r + 4, r + 10] = -24.0
+        for k in range(6):
+            A[r + 5, r + k] = pw[k]
+            A[r + 6, r + k] = pw[k]
+        A[r + 6, r + 6] = -1.0
+        for k in range(1, 6):
+            A[r + 7, r + k] = k * pw[k - 1]
+        A[r + 7, r + 7] = -1.0
+        for k in range(2, 6):
+            A[r + 8, r + k] = k * (k - 1) * pw[k - 2]
+        A[r + 8, r + 8] = -2.0
+        b[r + 5] = q[i]
+    r = 6 * (N - 1)
+    for k in range(6):
+        A[6 * N - 3, r + k] = pw[k]
+    for k in range(1, 6):
+        A[6 * N - 2, r + k] = k * pw[k - 1]
+    for k in range(2, 6):
+        A[6 * N - 1, r + k] = k * (k - 1) * pw[k - 2]
+    b[6 * N - 3:] = tail
+    return torch.linalg.solve(A, b).reshape(N, 6, D)
+
+
+def jerk_energy(c, T):
+    """sum over pieces and dimensions of int_0^T (6 c3 + 24 c4 t + 60 c5 t^2)^2 dt, integrated by hand"""
+    c3, c4, c5 = c[:, 3], c[:, 4], c[:, 5]
+    return (36.0 * c3 * c3 * T + 144.0 * c3 * c4 * T ** 2 + (192.0 * c4 * c4 + 240.0 * c3 * c5) * T ** 3 + 720.0 * c4 * c5 * T ** 4
+            + 720.0 * c5 * c5 * T ** 5).sum()
+
+
+def terrain(cells, pos):
+    """cells (nx, ny, nyaw, 4) tensor {z, sigma, zbx, zby}; pos (S, 3) with wrapped yaw -> sigma, zbx, zby (S,) differentiable in pos"""
+    nx, ny, nyaw = cells.shape[:3]
+    rx, rw = GRID["xy_res"], GRID["yaw_res"]
+    size = np.array([GRID["size_x"], GRID["size_y"], 2.0 * math.pi + 5e-2])
+    org = -size / 2.0
+    p = pos.detach().numpy()
+    inmap = np.all(p >= (org + 1e-4), axis=1) & np.all(p <= (-org - 1e-4), axis=1)                 # uneven_map.h:437-454
+    pm = p - np.array([0.5 * rx, 0.5 * rx, 0.5 * rw])
+    pm[:, 2] = np.arctan2(np.sin(pm[:, 2]), np.cos(pm[:, 2]))                                      # normSO2
+    inv = np.array([1.0 / rx, 1.0 / rx, 1.0 / rw])
+    idx = np.floor((pm - org) * inv).astype(np.int64)                                              # posToIndex :411-417
+    ctr = (idx + 0.5) * np.array([rx, rx, rw]) + org                                               # indexToPos :419-425
+    ctr_t = torch.from_numpy(ctr)
+    dx = (pos[:, 0] - ctr_t[:, 0]) / rx
+    dy = (pos[:, 1] - ctr_t[:, 1]) / rx
+    dw_ = pos[:, 2] - ctr_t[:, 2]
+    dw = torch.atan2(torch.sin(dw_), torch.cos(dw_)) / rw
+
+    def corner(a, b, c):
+        ix = np.clip(idx[:, 0] + a, 0, nx - 1)
+        iy = np.clip(idx[:, 1] + b, 0, ny - 1)
+        iw = np.mod(idx[:, 2] + c, nyaw)                                                           # boundIndex :398-409 (yaw wraps modulo the bin count)
+        return cells[ix, iy, iw]                                                                   # (S, 4)
+    v00 = corner(0, 0, 0) * (1 - dx)[:, None] + corner(1, 0, 0) * dx[:, None]
+    v01 = corner(0, 0, 1) * (1 - dx)[:, None] + corner(1, 0, 1) * dx[:, None]
+    v10 = corner(0, 1, 0) * (1 - dx)[:, None] + corner(1, 1, 0) * dx[:, None]
+    v11 = corner(0, 1, 1) * (1 - dx)[:, None] + corner(1, 1, 1) * dx[:, None]
+    v0 = v00 * (1 - dy)[:, None] + v10 * dy[:, None]
+    v1 = v01 * (1 - dy)[:, None] + v11 * dy[:, None]
+    val = v0 * (1 - dw)[:, None] + v1 * dw[:, None]
+    val = torch.where(torch.from_numpy(inmap)[:, None], val, torch.zeros_like(val))                # outside the map: RXS2() zeros (:260-265)
+    return val[:, 1], val[:, 2], val[:, 3]
+
+
+def objective(x, prob, cells, lam, mu, scale_cx, rho, scale_fx, use_scaling=True):
+    """x = [tau | Pxy (2 x (Nxy-1), column-major) | Pyaw]; lam (S,), mu (S, 6), scale_cx (S, 7).  Returns f, parts, hx, gx, Q3 sum"""
+    Nxy = prob["inner_xy"].shape[1] + 1
+    Nyaw = prob["inner_yaw"].shape[0] + 1
+    K = P["int_K"]
+    tau = x[0]
+    qxy = x[1:1 + 2 * (Nxy - 1)].reshape(Nxy - 1, 2)
+    qyaw = x[1 + 2 * (Nxy - 1):].reshape(Nyaw - 1, 1)
+    Ttot = expC2(tau)
+    Txy, Tyaw = Ttot / Nxy, Ttot / Nyaw
+    cxy = minco(qxy, Txy, torch.from_numpy(prob["init_xy"].T.copy()), torch.from_numpy(prob["end_xy"].T.copy()))
+    cyaw = minco(qyaw, Tyaw, torch.from_numpy(prob["init_yaw"].reshape(3, 1).copy()), torch.from_numpy(prob["end_yaw"].reshape(3, 1).copy()))
+    jerk = jerk_energy(cxy, Txy) + jerk_energy(cyaw, Tyaw)
+    jerk_cost = jerk * scale_fx * (P["scale_trick_jerk"] if use_scaling else 1.0)
+    tau_cost = P["rho_T"] * Ttot * scale_fx
+    # samples: piece i, j = 0..K at in-piece time j/K * Txy
+    ii = torch.arange(Nxy).repeat_interleave(K + 1)
+    jj = torch.arange(K + 1).repeat(Nxy)
+    alpha = jj.to(torch.float64) / K
+    s = alpha * Txy
+    pw = torch.stack([s ** k for k in range(6)], dim=1)                                            # (S, 6)
+    c = cxy[ii]                                                                                    # (S, 6, 2)
+    pos = (c * pw[:, :, None]).sum(1)
+    d1 = torch.stack([k * s ** (k - 1) if k >= 1 else torch.zeros_like(s) for k in range(6)], dim=1)
+    d2 = torch.stack([k * (k - 1) * s ** (k - 2) if k >= 2 else torch.zeros_like(s) for k in range(6)], dim=1)
+    vel = (c * d1[:, :, None]).sum(1)
+    acc = (c * d2[:, :, None]).sum(1)
+    now = (ii.to(torch.float64) + alpha) * Txy
+    yi = torch.clamp(torch.floor(now.detach() / Tyaw.detach()).to(torch.int64), max=Nyaw - 1)     # yaw_idx (:749-751)
+    sy = now - yi.to(torch.float64) * Tyaw
+    cw = cyaw[yi][:, :, 0]                                                                         # (S, 6)
+    yaw = (cw * torch.stack([sy ** k for k in range(6)], dim=1)).sum(1)
+    dyaw = (cw * torch.stack([k * sy ** (k - 1) if k >= 1 else torch.zeros_like(sy) for k in range(6)], dim=1)).sum(1)
+    yawn = torch.atan2(torch.sin(yaw), torch.cos(yaw))                                             # normSO2 of the lookup pose (:767)
+    sig, zx, zy = terrain(cells, torch.stack([pos[:, 0], pos[:, 1], yawn], dim=1))
+    syaw, cyw = torch.sin(yaw), torch.cos(yaw)
+    cc = torch.sqrt(1.0 - zx * zx - zy * zy)
+    cn, sn = torch.cos(yawn), torch.sin(yawn)
+    t = cn * zx + sn * zy
+    ss = -(-sn * zx + cn * zy)
+    sq = torch.sqrt(1.0 - t * t)
+    icvx, sphx, icvy, sphy, cxi, icxi = 1.0 / sq, -cc * t / sq, sq / cc, ss / sq, cc, 1.0 / cc     # uneven_map.h:343-348
+    vnorm = torch.sqrt(vel[:, 0] ** 2 + vel[:, 1] ** 2)
+    lon = acc[:, 0] * cyw + acc[:, 1] * syaw
+    lat = -acc[:, 0] * syaw + acc[:, 1] * cyw
+    vx = vnorm * icvx
+    wz = dyaw * icxi
+    ax = lon * icvx + P["gravity"] * sphx
+    ay = lat * icvy + P["gravity"] * sphy
+    curv = wz * wz / (vx * vx + P["delta_sigl"])
+    step = Txy / K
+    omega = torch.where((jj == 0) | (jj == K), 0.5, 1.0) * P["rho_ter"] * step * scale_fx
+    user = omega * sig * sig
+    sc = torch.from_numpy(scale_cx)
+    hx = (vel[:, 0] * syaw - vel[:, 1] * cyw) * sc[:, 0]
+    lam_t, mu_t = torch.from_numpy(lam), torch.from_numpy(mu)
+    cost = user.sum() + (hx * (lam_t + 0.5 * rho * hx)).sum()
+    sc_cur = sc[:, 4] if use_scaling else torch.full_like(sc[:, 4], 10.0)
+    sc_sig = sc[:, 6] if use_scaling else torch.full_like(sc[:, 6], 1000.0)
+    gx = torch.stack([(vx * vx - P["max_vel"] ** 2) * sc[:, 1], (ax * ax - P["max_acc_lon"] ** 2) * sc[:, 2], (ay * ay - P["max_acc_lat"] ** 2) * sc[:, 3],
+                      (curv - P["max_kap"] ** 2) * sc_cur, (P["min_cxi"] - cxi) * sc[:, 5], (sig - P["max_sig"]) * sc_sig], dim=1)
+    active = rho * gx + mu_t > 0
+    cost = cost + torch.where(active, gx * (mu_t + 0.5 * rho * gx), -0.5 * mu_t * mu_t / rho).sum()
+    # Q3: the reference adds user_cost / int_K to gdTxy(i) where the derivative of omega (proportional to Txy) gives user_cost / Txy
+    q3 = (user.detach() * (1.0 / K - 1.0 / Txy.detach())).sum()
+    return jerk_cost + cost + tau_cost, (jerk_cost, cost, tau_cost), hx, gx, q3, Nxy
+
+
+def main():
+    from uneven_planner_amd import scenes
+    cells_np = scenes.analytic_cells()
+    nx, ny, nyaw = scenes.grid_dims()
+    cells = torch.from_numpy(cells_np.reshape(nx, ny, nyaw, 4).copy())
+    out = {}
+    cases = [("hill", scenes.hill_problem())] + [("rand%d" % i, p) for i, p in enumerate(scenes.random_problems(3, seed0=2003, dmin=3.0, dmax=6.0))]
+    for ci, (name, prob) in enumerate(cases):
+        Nxy, Nyaw = prob["inner_xy"].shape[1] + 1, prob["inner_yaw"].shape[0] + 1
+        S = Nxy * (P["int_K"] + 1)
+        rng = np.random.default_rng(700 + ci)
+        tau0 = math.sqrt(2.0 * prob["total_time"] - 1.0) - 1.0 if prob["total_time"] > 1.0 else 1.0 - math.sqrt(2.0 / prob["total_time"] - 1.0)
+        x0 = np.concatenate([[tau0], prob["inner_xy"].T.ravel(), prob["inner_yaw"]])
+        x0 = x0 + 0.02 * rng.normal(size=x0.size)
+        lam = 0.3 * rng.normal(size=S)
+        mu = np.abs(0.3 * rng.normal(size=(S, 6)))
+        scale_cx = rng.uniform(0.2, 1.0, size=(S, 7))
+        rho, scale_fx = 3.0, 0.37
+        x = torch.tensor(x0, requires_grad=True)
+        f, parts, hx, gx, q3, _ = objective(x, prob, cells, lam, mu, scale_cx, rho, scale_fx)
+        f.backward()
+        g = x.grad.detach().numpy().copy()
+        tau = x0[0]
+        dT = (tau + 1.0) if tau > 0 else (1.0 - tau) / ((0.5 * tau - 1.0) * tau + 1.0) ** 2             # dT/dtau of expC2
+        g[0] += float(q3) / Nxy * dT                                                                    # Q3, through grad_Tsum = ... + gdTxy.sum() / piece_xy
+        for k, v in dict(x=x0, lam=lam, mu=mu, scale_cx=scale_cx, rho=np.array(rho), scale_fx=np.array(scale_fx), f=np.array(float(f.detach())),
+                         parts=np.array([float(p_.detach()) for p_ in parts]), grad=g, hx=hx.detach().numpy(), gx=gx.detach().numpy(),
+                         init_xy=prob["init_xy"], end_xy=prob["end_xy"], inner_xy=prob["inner_xy"], init_yaw=prob["init_yaw"], end_yaw=prob["end_yaw"],
+                         inner_yaw=prob["inner_yaw"], total_time=np.array(prob["total_time"])).items():
+            out[name + "/" + k] = v
+        print(name, "n", x0.size, "f", float(f.detach()), "parts", [float(p_.detach()) for p_ in parts], "|grad|", np.abs(g).max())
+    np.savez_compressed(os.path.join(HERE, "objective_golden.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -239,3 +239,28 @@ def test_map_csv_roundtrip(oracle, tmp_path):
     assert oracle.lib().orc_map_read_csv(g2.h, path.encode()) == 0
     c2, _ = g2.get_cells()
     assert 0 < np.abs(c2 - cells).max() < 1e-5       # 6 significant digits of values up to 2
+
+
+def test_objective_and_gradient_match_the_autograd_model(oracle, oracle_grid):
+    """innerCallback + calConstrainCostGrad + the whole hand-written gradient chain (calJerkGradCT, the sample chain rule,
+    calGradCTtoQT through the banded LU, the tau map) against tests/golden/objective_golden.npz: an independent forward model in torch
+    with the gradient taken by autograd (tests/golden/make_objective_golden.py), plus the documented quirk Q3"""
+    z = np.load(os.path.join(G, "objective_golden.npz"))
+    names = sorted(set(k.split("/")[0] for k in z.files))
+    assert len(names) == 4
+    for nme in names:
+        g = lambda k: z[nme + "/" + k]
+        prob = dict(init_xy=g("init_xy"), end_xy=g("end_xy"), inner_xy=g("inner_xy"), init_yaw=g("init_yaw"), end_yaw=g("end_yaw"), inner_yaw=g("inner_yaw"),
+                    total_time=float(g("total_time")))
+        a = oracle.OracleALM(oracle_grid)
+        a.setup(prob)
+        a.set_state(lam=g("lam"), mu=g("mu").ravel(), scale_cx=g("scale_cx").ravel(), scale_fx=float(g("scale_fx")))
+        a.set_rho(float(g("rho")))
+        f, gr, parts = a.eval(g("x"))
+        st = a.get_state()
+        assert abs(f - float(g("f"))) / abs(f) < 1e-12, (nme, f, float(g("f")))              # measured 2e-16 .. 5e-15
+        assert np.abs(gr - g("grad")).max() / np.abs(gr).max() < 1e-11, (nme, np.abs(gr - g("grad")).max() / np.abs(gr).max())       # measured < 1e-14
+        assert np.abs(gr[1:] - g("grad")[1:]).max() / np.abs(gr[1:]).max() < 1e-11         # way-point entries on their own
+        assert abs(gr[0] - g("grad")[0]) / abs(gr[0]) < 1e-11                                   # tau entry (carries quirk Q3)
+        assert np.abs(st["hx"] - g("hx")).max() < 1e-10 * max(1.0, np.abs(g("hx")).max())
+        assert np.abs(st["gx"].reshape(-1, 6) - g("gx")).max() < 1e-10 * max(1.0, np.abs(g("gx")).max())
