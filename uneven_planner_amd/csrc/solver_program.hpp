@@ -34,6 +34,9 @@
 namespace uph {
 
 // scatter batch widths (LDS reads in flight per lane): xy blocks hold K + 1 = 17 records, yaw candidates ~40
+#ifndef UPH_GRID_FROM_MEM
+#define UPH_GRID_FROM_MEM 1
+#endif
 #ifndef UPH_SC_XB
 #define UPH_SC_XB 9
 #endif
@@ -273,7 +276,22 @@ struct Solver {
     // gradients are never formed individually (sampleEval folds them into four scalar coefficients)
     UPH_HD void terrainValuesOnly(Kin& S_) const {
         double sg;
+#if defined(__HIP_DEVICE_COMPILE__) && UPH_GRID_FROM_MEM
+        // the grid descriptor through an opaque constant-address-space pointer: scalar loads issued here, nothing for the compiler to
+        // keep live (and spill to VGPR lanes) across the solver's loops
+        typedef const __attribute__((address_space(4))) unsigned long long* gw_t;
+        gw_t T = (gw_t)(const void*)bd.grid_mem;
+        asm volatile("" : "+s"(T));
+        constexpr int NWORD = (int)(sizeof(GridDev) / 8);
+        unsigned long long w[NWORD];
+#pragma unroll
+        for (int k = 0; k < NWORD; k++) w[k] = T[k];
+        GridDev gl;
+        __builtin_memcpy(&gl, w, sizeof(GridDev));
+        terrainBase(gl, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
+#else
         terrainBase(grid, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
+#endif
         const double zx = S_.zx, zy = S_.zy;
         const double cc = sqrt(1.0 - zx * zx - zy * zy);                 // uneven_map.h:327-348
         const double inv_c = 1.0 / cc;
