@@ -815,20 +815,25 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         for (int i = 0; i < 2 * pr.n_inner_xy; i++) x[1 + i] = pr.inner_xy[i];
         for (int i = 0; i < pr.n_inner_yaw; i++) x[1 + 2 * pr.n_inner_xy + i] = pr.inner_yaw[i];
     }
-    // Launch order: most expensive solves first (longest-processing-time list scheduling), so that the tail of a large batch is
-    // made of short solves.  Predicted cost = n * exp(0.23 * total heading change of the initial path): a log-linear fit on the
-    // hill-scene batches (R^2 0.79 against measured solve cycles, vs 0.43 for n alone) -- winding initial paths need more ALM /
-    // L-BFGS iterations.  A simulated 1024-slot schedule of the measured B = 8192 solve times gives 302 ms for this order, 328 ms
-    // for n-descending, 273 ms for the unattainable perfect order.  Placement never affects results.
-    // (Tried and dropped: cutting the sorted list into per-XCD chunks for L2 locality of the operators -- 8 % slower.)
+    // Launch order: most expensive solves first (longest-processing-time list scheduling), so that the tail of a launch -- workgroups
+    // finishing below full residency -- is made of short solves.  Predicted cost = n^0.83 exp(0.13 turn) (1 + kink)^0.41 with n = number of
+    // variables, turn = total heading change of the initial path and kink = its largest heading change between two consecutive yaw
+    // way-points (sharp corners of the initial path are what needs many ALM passes): a log-linear fit on 8192 hill-scene solves
+    // (tools/collect_cost_features.py; R^2 0.83 on held-out problems, 0.77 without the kink term).  A simulated 1024-slot schedule of the
+    // measured solve times at B = 8192 gives 164 ms for this order, 186 ms for the round-1 model n exp(0.23 turn), 196 ms for
+    // n-descending and 163.4 ms for the unattainable perfect order; at B = 16384: 324.0 / 329.1 / 352.6 / 323.5 ms.  Placement never
+    // affects results.  (Tried and dropped: cutting the sorted list into per-XCD chunks for L2 locality -- 8 % slower.)
     {
         std::vector<double> cost(B);
         for (int b = 0; b < B; b++) {
             const uph_problem& pr = *pp[b];
-            double turn = 0.0, prev = pr.init_yaw[0];
-            for (int i = 0; i < pr.n_inner_yaw; i++) { turn += std::fabs(pr.inner_yaw[i] - prev); prev = pr.inner_yaw[i]; }
-            turn += std::fabs(pr.end_yaw[0] - prev);
-            cost[b] = (double)c->desc[b].n * std::exp(0.23 * turn);
+            double turn = 0.0, kink = 0.0, prev = pr.init_yaw[0];
+            for (int i = 0; i <= pr.n_inner_yaw; i++) {
+                const double cur = i < pr.n_inner_yaw ? pr.inner_yaw[i] : pr.end_yaw[0];
+                const double dy = std::fabs(cur - prev);
+                turn += dy; kink = std::max(kink, dy); prev = cur;
+            }
+            cost[b] = std::pow((double)c->desc[b].n, 0.831) * std::exp(0.129 * turn) * std::pow(1.0 + kink, 0.408);
         }
         c->order.resize(B);
         std::iota(c->order.begin(), c->order.end(), 0);
