@@ -39,3 +39,26 @@ def test_full_batch_is_deterministic_order_independent_and_equals_small_batches(
     rep = opt.getMaxVxAxAyCurAttSig()
     conv = rets == 0
     assert np.all(np.abs(rep[conv, 0]) < 0.5 * 1.05) and np.all(rep[conv, 5] < 0.05 * 1.1)      # max_vel, max_sig of run_hill.yaml
+
+
+def test_kernel_selection_boundaries():
+    """the batch sizes at which uph_batch_upload switches kernels (256 lanes uncapped below 512, 256 lanes with the register cap from 512,
+    128 lanes from 2304): every variant must solve, and the objective at the common starting points must agree to rounding"""
+    import uneven_planner_amd as U
+    from uneven_planner_amd import scenes
+    from conftest import rel
+    m = U.UnevenMap()
+    m.set_cells(scenes.analytic_cells())
+    probs = scenes.random_problems(2304, seed0=3000, dmin=3.0, dmax=6.0)
+    ref_f = ref_g = None
+    for Bx in (1, 2, 511, 512, 2303, 2304):
+        opt = U.ALMTrajOpt(m)
+        opt.upload(probs[:Bx])
+        f, g = opt.eval_batch(opt.x0_packed(probs[:Bx]))
+        if ref_f is None:
+            ref_f, ref_g = f[0], g[0]
+        assert abs(f[0] - ref_f) / abs(ref_f) < 1e-12 and rel(ref_g, g[0]) < 1e-11, Bx
+        opt.set_rho(1.0)
+        opt.solve()
+        out = opt.download()
+        assert all(o["ret"] in (0, 2) for o in out), Bx
