@@ -582,12 +582,7 @@ struct Solver {
         int m0 = rtag[0] - 1, m1 = rtag[cnt - 1] + 1;
         if (m0 < 0) m0 = 0;
         if (m1 > Nyaw - 1) m1 = Nyaw - 1;
-#ifdef UPH_SC_TEST          // timing experiment only (wrong results): 1 = xy part alone, 2 = yaw part alone
-        wg.pfor(UPH_SC_TEST == 1 ? XYL : XYL + 3 * (m1 - m0 + 1), [&](int t) {
-            if (UPH_SC_TEST == 2 && t < XYL) return;
-#else
         wg.pfor(XYL + 3 * (m1 - m0 + 1), [&](int t) {
-#endif
             if (t < XYL) {
                 if (t >= nxyt) return;
                 const int pi = t / 6, r = t - 6 * pi, dd = r & 1, kp = r >> 1;      // r = 2 kp + dd

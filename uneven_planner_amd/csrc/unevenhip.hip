@@ -412,9 +412,6 @@ struct DevWG {
         __syncthreads();
     }
     __device__ __forceinline__ void thomas(const double* tab, bool adj, double* bw, int lenW, double* bx, int lenX) {
-#ifdef UPH_NO_THOMAS       // timing experiment only (wrong results): what the knot solves cost under load
-        sync(); return;
-#endif
         if (adj) thomasT<true>(tab, bw, lenW, bx, lenX);
         else thomasT<false>(tab, bw, lenW, bx, lenX);
     }
