@@ -8,9 +8,14 @@ sys.path.insert(0, os.getcwd())
 import uneven_planner_amd as U
 from uneven_planner_amd import scenes
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-m = U.UnevenMap(); m.build(scenes.make_hill_cloud())
-nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
-probs = scenes.random_problems(B, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
+if len(sys.argv) > 2 and sys.argv[2] == "km2":        # BASELINE.json configs[4] scene (256 m square is enough for the statistics)
+    from uneven_planner_amd.uneven_map import km2_map, km2_problems
+    m = km2_map(256.0)
+    probs = km2_problems(m, 256.0, B, 0)
+else:
+    m = U.UnevenMap(); m.build(scenes.make_hill_cloud())
+    nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
+    probs = scenes.random_problems(B, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
 opt = U.ALMTrajOpt(m); opt.upload(probs)
 opt.init_scaling_batch()
 rep0 = opt.getMaxVxAxAyCurAttSig()

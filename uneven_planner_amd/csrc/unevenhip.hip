@@ -607,16 +607,16 @@ static int launchSolver(uph_ctx* c, int mode, int repeat) {
         HIPCHK(hipEventRecord(c->ev0, c->stream));                                                                                   \
         BatchDev bm = bd;                                                                                                            \
         bm.B = c->n_main;                                                                                                            \
-        hipLaunchKernelGGL((uph_solver_kernel<NTL, WPS, MODE>), dim3(c->n_main), dim3(NTL), c->lds_bytes, c->stream, grid, c->P, bm, repeat); \
-        if (c->n_main < c->B) {                          /* oversize class: same kernel, own LDS size, concurrent on stream2 */     \
-            BatchDev bb = bd;                                                                                                        \
+        if (c->n_main < c->B) {           /* oversize class: same kernel, own LDS size, concurrent on the high-priority stream2 and */ \
+            BatchDev bb = bd;             /* submitted first: these are the longest solves of the batch (longest-first scheduling)  */ \
             bb.B = c->B - c->n_main;                                                                                                 \
             bb.order = bd.order + c->n_main;                                                                                         \
             HIPCHK(hipStreamWaitEvent(c->stream2, c->ev0, 0));                                                                       \
             hipLaunchKernelGGL((uph_solver_kernel<NTL, WPS, MODE>), dim3(bb.B), dim3(NTL), c->lds_big, c->stream2, grid, c->P, bb, repeat); \
             HIPCHK(hipEventRecord(c->ev2, c->stream2));                                                                              \
-            HIPCHK(hipStreamWaitEvent(c->stream, c->ev2, 0));                                                                        \
         }                                                                                                                            \
+        hipLaunchKernelGGL((uph_solver_kernel<NTL, WPS, MODE>), dim3(c->n_main), dim3(NTL), c->lds_bytes, c->stream, grid, c->P, bm, repeat); \
+        if (c->n_main < c->B) HIPCHK(hipStreamWaitEvent(c->stream, c->ev2, 0));                                                      \
     } while (0)
 #define UPH_LAUNCH_MODE(NTL, WPS)                                                                                                      \
     do {                                                                                                                             \
@@ -686,7 +686,11 @@ int uph_ctx_create(uph_map* m, const uph_opt_params* p, uph_ctx** out) {
         if (hipMemcpy(c->d_thomas.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { setError("hipMemcpy(thomas table) failed"); c->d_thomas.release(); delete c; return UPH_ERR_HIP; }
     }
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {
+        int prio_lo = 0, prio_hi = 0;
+        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          // (numerically lowest = highest priority)
+        HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi));
+    }
     HIPCHK(hipEventCreate(&c->ev2));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
