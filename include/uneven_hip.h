@@ -219,8 +219,8 @@ void uph_ctx_destroy(uph_ctx* c);
 /* rho is a member that persists across solves in the reference (alm_traj_opt.cpp:16, alm_traj_opt.h:137): every problem of a
  * batch starts from the context's rho.  After a solve of ONE problem the context's rho is that problem's final rho (the reference's
  * behaviour over consecutive calls); a batch of B > 1 independent problems leaves it unchanged (each result carries its rho_final). */
-/* lanes of one workgroup that cooperate on ONE trajectory: 64, 128 or 256 (one, two or four wave64); 0 = automatic (default):
- * 128 lanes with up to four workgroups per CU from 2304 problems (throughput), 256 lanes below (latency).  Takes effect at the next
+/* lanes of one workgroup that cooperate on ONE trajectory: 64, 128, 256 or 512 (one, two, four or eight wave64); 0 = automatic (default):
+ * 128 lanes with up to four workgroups per CU from 2304 problems (throughput), 256 lanes below, 512 lanes up to 256 problems (latency).  Takes effect at the next
  * upload.  Results do not depend on the choice beyond the summation order of the block reductions. */
 int uph_ctx_set_lanes(uph_ctx* c, int32_t lanes);
 /* experiment knob: 2 = register-capped kernel build (two waves per SIMD), 1 = uncapped, 0 = choose from the batch size */

@@ -42,7 +42,7 @@ def test_full_batch_is_deterministic_order_independent_and_equals_small_batches(
 
 
 def test_kernel_selection_boundaries():
-    """the batch sizes at which uph_batch_upload switches kernels (256 lanes uncapped below 512, 256 lanes with the register cap from 512,
+    """the batch sizes at which uph_batch_upload switches kernels (512 lanes up to 256 problems, 256 lanes uncapped below 512, 256 lanes with the register cap from 512,
     128 lanes from 2304): every variant must solve, and the objective at the common starting points must agree to rounding"""
     import uneven_planner_amd as U
     from uneven_planner_amd import scenes
@@ -51,7 +51,7 @@ def test_kernel_selection_boundaries():
     m.set_cells(scenes.analytic_cells())
     probs = scenes.random_problems(2304, seed0=3000, dmin=3.0, dmax=6.0)
     ref_f = ref_g = None
-    for Bx in (1, 2, 511, 512, 2303, 2304):
+    for Bx in (1, 2, 256, 257, 511, 512, 2303, 2304):
         opt = U.ALMTrajOpt(m)
         opt.upload(probs[:Bx])
         f, g = opt.eval_batch(opt.x0_packed(probs[:Bx]))

@@ -12,7 +12,7 @@ from conftest import rel
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [(64, 1), (64, 2), (128, 2), (256, 1), (256, 2)]
+VARIANTS = [(64, 1), (64, 2), (128, 2), (256, 1), (256, 2), (512, 1)]
 
 
 @pytest.fixture(scope="module")

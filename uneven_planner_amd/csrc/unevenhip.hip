@@ -635,6 +635,7 @@ static int launchSolver(uph_ctx* c, int mode, int repeat) {
     else if (c->lanes == 64 && c->wps_forced == 2) UPH_LAUNCH_MODE(64, 2);
     else if (c->lanes == 64) UPH_LAUNCH_MODE(64, 1);
     else if (c->lanes == 128) UPH_LAUNCH_MODE(128, 2);
+    else if (c->lanes == 512) UPH_LAUNCH_MODE(512, 1);
     else if (c->wps == 2 && mode == 2 && c->lds_bytes <= 80 * 1024) UPH_LAUNCH(256, 2, 2);
     else if (c->wps == 2 && mode == 5 && c->lds_bytes <= 80 * 1024) UPH_LAUNCH(256, 2, 5);
     else UPH_LAUNCH_MODE(256, 1);
@@ -715,7 +716,7 @@ void uph_ctx_destroy(uph_ctx* c) {
 
 // lanes cooperating on one trajectory: 64, 256, or 0 = pick from the batch size (takes effect at the next upload)
 int uph_ctx_set_lanes(uph_ctx* c, int32_t lanes) {
-    if (!c || (lanes != 0 && lanes != 64 && lanes != 128 && lanes != 256)) return UPH_ERR_INVALID;
+    if (!c || (lanes != 0 && lanes != 64 && lanes != 128 && lanes != 256 && lanes != 512)) return UPH_ERR_INVALID;
     c->lanes_forced = lanes;
     return UPH_OK;
 }
@@ -744,7 +745,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     // small batches: four waves per trajectory (latency); large batches: two waves per trajectory, up to four trajectories resident
     // per CU (throughput; crossover measured between 2048 and 2560 trajectories on 256 CUs: below it the batch time is the longest
     // trajectory's own latency, which four waves halve)
-    c->lanes = c->lanes_forced ? c->lanes_forced : (B >= 2304 ? 128 : 256);
+    c->lanes = c->lanes_forced ? c->lanes_forced : (B >= 2304 ? 128 : (B <= 256 ? 512 : 256));      // up to one trajectory per CU: eight waves each (shortest latency)
     c->wps = c->wps_forced ? c->wps_forced : ((B >= 512) ? 2 : 1);
     c->fp_bytes.assign(B, 0);
     // A problem outside the compiled limits (no inner way-point in a block: a goal closer than one piece length; more pieces than
@@ -842,7 +843,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         // Residency classes.  One launch has one LDS size, and the largest trajectory of a batch would set it for all: at 128 lanes
         // a single 41 KB trajectory among 8192 pushes everybody from four workgroups per CU to three (-16 %).  Trajectories above
         // the residency limit therefore form a second class that is launched concurrently on a second stream with its own size.
-        const size_t limit = c->lanes == 128 ? 40960 : (c->lanes == 256 ? 81920 : 32768);      // 4, 2 and 5 workgroups per CU
+        const size_t limit = c->lanes == 128 ? 40960 : (c->lanes == 256 ? 81920 : (c->lanes == 512 ? 163840 : 32768));      // 4, 2, 1 and 5 workgroups per CU
         c->n_main = B; c->lds_big = 0;
         size_t mmain = 0, mbig = 0;
         int nbig = 0;
