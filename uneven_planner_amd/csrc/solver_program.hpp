@@ -403,15 +403,29 @@ struct Solver {
         const double vx = k.vx, wz = k.wz, ax = k.ax, ay = k.ay, curv = k.curv_snorm;
         const double nh0 = k.syaw, nh1 = -k.cyaw;
         // residuals: non-holonomic :830-835, then g1..g6 :841-946 (Q6: without use_scaling only curvature and sigma take fixed scales)
+#if defined(__HIP_DEVICE_COMPILE__) && UPH_GRID_FROM_MEM
+        // the limits through an opaque constant-address-space pointer (scalar loads here instead of SGPRs held, and spilled, across the solve)
+        typedef const __attribute__((address_space(4))) unsigned long long* pw_t;
+        pw_t PT = (pw_t)(const void*)bd.params_mem;
+        asm volatile("" : "+s"(PT));
+        constexpr int PWORD = (int)(sizeof(OptParams) / 8);
+        unsigned long long pw[PWORD];
+#pragma unroll
+        for (int q = 0; q < PWORD; q++) pw[q] = PT[q];
+        OptParams Pm;
+        __builtin_memcpy(&Pm, pw, sizeof(OptParams));
+#else
+        const OptParams& Pm = P;
+#endif
         const double h = (k.vel[0] * nh0 + k.vel[1] * nh1) * sc7[0];
-        const double g1 = (vx * vx - P.max_vel2) * sc7[1];
-        const double g2 = (ax * ax - P.max_acc_lon2) * sc7[2];
-        const double g3 = (ay * ay - P.max_acc_lat2) * sc7[3];
-        const double sc4 = P.use_scaling ? sc7[4] : cur_scale;
-        const double g4 = (curv - P.max_kap2) * sc4;
-        const double g5 = (P.min_cxi - cos_xi) * sc7[5];
-        const double sc6 = P.use_scaling ? sc7[6] : sig_scale;
-        const double g6 = (sigma - P.max_sig) * sc6;
+        const double g1 = (vx * vx - Pm.max_vel2) * sc7[1];
+        const double g2 = (ax * ax - Pm.max_acc_lon2) * sc7[2];
+        const double g3 = (ay * ay - Pm.max_acc_lat2) * sc7[3];
+        const double sc4 = Pm.use_scaling ? sc7[4] : cur_scale;
+        const double g4 = (curv - Pm.max_kap2) * sc4;
+        const double g5 = (Pm.min_cxi - cos_xi) * sc7[5];
+        const double sc6 = Pm.use_scaling ? sc7[6] : sig_scale;
+        const double g6 = (sigma - Pm.max_sig) * sc6;
         if (RES_ONLY) {
             res[0 * S + s] = h; res[1 * S + s] = g1; res[2 * S + s] = g2; res[3 * S + s] = g3;
             res[4 * S + s] = g4; res[5 * S + s] = g5; res[6 * S + s] = g6;

@@ -529,7 +529,7 @@ struct uph_ctx {
     int lanes_forced = 0;                   // 0 = choose from the batch size
     int wps = 1;                            // workgroups of 256 lanes per CU the kernel is compiled for (1 or 2)
     int wps_forced = 0;                     // experiment knob: register-capped (2) or uncapped (1) build regardless of batch size
-    DevBuf d_thomas, d_rsd, d_rs, d_gridmem;
+    DevBuf d_thomas, d_rsd, d_rs, d_gridmem, d_parammem;
     GridDev grid_host;                      // source of the descriptor copy (outlives the asynchronous copy)
     DevBuf d_desc, d_state, d_x, d_x0, d_gout, d_dual, d_res, d_scl, d_cxy, d_cyaw, d_hist, d_report, d_order, d_trace;
     int trace_cap = 0;                      // requested for the next upload
@@ -566,6 +566,7 @@ static BatchDev makeBatchDev(uph_ctx* c) {
     bd.order = c->d_order.as<int>();
     bd.thomas = c->d_thomas.as<double>();
     bd.grid_mem = c->d_gridmem.as<GridDev>();
+    bd.params_mem = c->d_parammem.as<OptParams>();
     bd.rs_d = c->d_rsd.as<double>(); bd.rs = c->d_rs.as<double>();
     return bd;
 }
@@ -597,6 +598,8 @@ static int launchSolver(uph_ctx* c, int mode, int repeat) {
     if (c->d_gridmem.ensure(sizeof(GridDev))) return UPH_ERR_HIP;
     c->grid_host = grid;
     HIPCHK(hipMemcpyAsync(c->d_gridmem.p, &c->grid_host, sizeof(GridDev), hipMemcpyHostToDevice, c->stream));
+    if (c->d_parammem.ensure(sizeof(OptParams))) return UPH_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(c->d_parammem.p, &c->P, sizeof(OptParams), hipMemcpyHostToDevice, c->stream));
     BatchDev bd = makeBatchDev(c);
     // lanes/occupancy variants: <64,1> one wave per trajectory; <256,1> four waves, one workgroup per CU (no spills, lowest latency);
     // <256,2> four waves, registers capped at 256 so that two workgroups share a CU (best throughput for large batches)
@@ -704,7 +707,7 @@ void uph_ctx_destroy(uph_ctx* c) {
     hipSetDevice(c->device);             // not via c->map: the map may already have been destroyed by the caller
     for (void* p : c->op_allocs) hipFree(p);
     DevBuf* bufs[] = {&c->d_ops, &c->d_desc, &c->d_state, &c->d_x, &c->d_gout, &c->d_dual, &c->d_res, &c->d_scl, &c->d_cxy, &c->d_cyaw,
-                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas, &c->d_rsd, &c->d_rs, &c->d_gridmem};
+                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas, &c->d_rsd, &c->d_rs, &c->d_gridmem, &c->d_parammem};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);

@@ -147,6 +147,7 @@ struct BatchDev {
     double* trace;      // optional [B*trace_cap] diagnostic cost trace (nullptr = off)
     int trace_cap;
     const int* order;   // optional launch order: workgroup w solves trajectory order[w] (longest first)
+    const OptParams* params_mem;   // the optimiser parameters in device memory, for the same reason as grid_mem
     const GridDev* grid_mem;   // the grid descriptor in device memory (same content as the kernel argument): the penalty kernel re-reads it with scalar loads per sample chunk instead of holding ~50 SGPRs across the whole solve
     const double* thomas;   // block-LU factors of the MINCO knot system, THOMAS_DOUBLES (minco_op_host.hpp); shared by every trajectory, copied to LDS per workgroup
 };
