@@ -37,6 +37,17 @@ def test_desert_map_build_matches_oracle(desert, oracle):
         assert (d > 1e-9).mean() < 1e-3 and np.median(d) < 1e-12, ((d > 1e-9).mean(), d.max())
 
 
+def test_desert_cells_match_the_independent_numpy_fit(desert):
+    """the device plane fit against the numpy / eigh restatement of constructMap (tests/golden/mapcells_golden.npz): a second derivation,
+    not the oracle's Jacobi solver"""
+    _, m = desert
+    z = np.load(os.path.join(G, "mapcells_golden.npz"))
+    nx, ny, nyaw = (int(v) for v in m.voxel_num)
+    cells = m.map_buffer.reshape(nx, ny, nyaw, 4)
+    d = np.array([np.abs(cells[ix, iy, iw] - want).max() for (ix, iy, iw), want in zip(z["idx"], z["cells"])])
+    assert (d > 1e-9).sum() == 0 and np.median(d) < 1e-13, ((d > 1e-9).sum(), d.max())
+
+
 def test_desert_batch_256(desert, oracle):
     import uneven_planner_amd as U
     from uneven_planner_amd import scenes
