@@ -135,6 +135,39 @@ int orc_lbfgs_rosenbrock(int n, double* x, double* f_out, int mem_size, int past
     return r;
 }
 
+// L-BFGS on analytic test functions with the complete evaluation record: every point the algorithm evaluates (line-search trials
+// included), in order, with its value -- trace[e] = {x (n), f}.  kind 0: extended Rosenbrock; kind 1: ill-conditioned quadratic + quartic
+// coupling f = sum_i (1 + 3 i) (x_i - c_i)^2 + 0.05 sum_i (x_i x_{i+1})^2, c_i = sin(i + 1)
+int orc_lbfgs_trace(int kind, int n, double* x, int mem_size, int past, double g_eps, double delta, int max_iter, double* trace, int cap, int* evals, int* iters, double* f_out) {
+    LbfgsParam lp;
+    lp.mem_size = mem_size; lp.past = past; lp.g_epsilon = g_eps; lp.delta = delta; lp.min_step = 1e-32; lp.max_iterations = max_iter;
+    Vec xv(x, x + n);
+    int ne = 0;
+    EvalFn fn = [&](const Vec& xx, Vec& g) {
+        double fx = 0.0;
+        if (kind == 0) {
+            for (int i = 0; i < n; i += 2) {
+                double t1 = 1.0 - xx[i], t2 = 10.0 * (xx[i + 1] - xx[i] * xx[i]);
+                g[i + 1] = 20.0 * t2;
+                g[i] = -2.0 * (xx[i] * g[i + 1] + t1);
+                fx += t1 * t1 + t2 * t2;
+            }
+        } else {
+            for (int i = 0; i < n; i++) { const double w = 1.0 + 3.0 * i, d = xx[i] - std::sin(i + 1.0); fx += w * d * d; g[i] = 2.0 * w * d; }
+            for (int i = 0; i + 1 < n; i++) { const double p = xx[i] * xx[i + 1]; fx += 0.05 * p * p; g[i] += 0.1 * p * xx[i + 1]; g[i + 1] += 0.1 * p * xx[i]; }
+        }
+        if (ne < cap) { std::memcpy(trace + (size_t)ne * (n + 1), xx.data(), sizeof(double) * n); trace[(size_t)ne * (n + 1) + n] = fx; }
+        ne++;
+        return fx;
+    };
+    LbfgsStats st;
+    double f = 0;
+    int r = lbfgs_optimize(xv, f, fn, nullptr, lp, &st);
+    std::memcpy(x, xv.data(), sizeof(double) * n);
+    *f_out = f; *iters = st.iters; *evals = ne;
+    return r;
+}
+
 // ---------------- ALM optimiser
 struct OrcAlm { AlmTrajOpt opt; Vec x_last; };
 void* orc_alm_create(void* grid, const double* params21) {

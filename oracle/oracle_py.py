@@ -439,6 +439,22 @@ def lbfgs_rosenbrock(x0, mem_size=8, past=3, g_eps=1e-5, delta=1e-6):
     return r, x, f[0], it.value, ev.value
 
 
+def lbfgs_trace(kind, x0, mem_size=8, past=3, g_eps=1e-5, delta=1e-6, max_iter=10000, cap=4096):
+    """lbfgs_optimize on an analytic test function (0 Rosenbrock, 1 quadratic + quartic coupling) with the record of EVERY evaluation:
+    returns (ret, x, f, iters, evals, trace (evals, n + 1))"""
+    L = lib()
+    x = _f64(x0).copy()
+    n = x.size
+    tr = np.zeros((cap, n + 1))
+    f = np.zeros(1)
+    it, ev = C.c_int(0), C.c_int(0)
+    L.orc_lbfgs_trace.restype = C.c_int
+    L.orc_lbfgs_trace.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.c_int,
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    r = L.orc_lbfgs_trace(int(kind), n, _dp(x), int(mem_size), int(past), float(g_eps), float(delta), int(max_iter), _dp(tr), cap, C.byref(ev), C.byref(it), _dp(f))
+    return r, x, f[0], it.value, ev.value, tr[:min(ev.value, cap)]
+
+
 def resample(path, params=None):
     """plan_manager.cpp:62-132 through the C++ restatement (oracle/resample.hpp): path (M,3) -> the optimizeSE2Traj argument dict
     (+ "yaw_unwrapped")"""

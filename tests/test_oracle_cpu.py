@@ -284,3 +284,26 @@ def test_map_cells_match_the_independent_numpy_fit_on_the_desert_cloud(oracle):
             worst = np.maximum(worst, d)
     # a fit whose point set differs by one borderline point (float predicate at the search radius) would be off by ~1e-3; none may be
     assert bad == 0 and worst.max() < 1e-10, (bad, worst)
+
+
+def test_lbfgs_evaluates_the_same_points_as_the_independent_numpy_implementation(oracle):
+    """lbfgs.hpp restated twice: the oracle (C++) and tests/golden/make_lbfgs_golden.py (numpy, written from the header).  The record of
+    EVERY evaluation -- line-search trials included, in order -- must coincide: same count, same points, same return code.  Cases wrap the
+    history ring (mem_size 2 / 3), switch the past-test off, hit the iteration limit and run the non-upstream early accept."""
+    z = np.load(os.path.join(G, "lbfgs_golden.npz"))
+    names = sorted(set(k.split("/")[0] for k in z.files))
+    assert len(names) == 6
+    for nme in names:
+        kind, n, m, past, geps, delta, maxit = z[nme + "/cfg"]
+        r, x, f, it, ev, tr = oracle.lbfgs_trace(int(kind), z[nme + "/x0"], mem_size=int(m), past=int(past), g_eps=float(geps), delta=float(delta),
+                                                 max_iter=int(maxit) if maxit else 0)
+        rec = z[nme + "/rec"]
+        scale = np.maximum(1.0, np.abs(rec))
+        if kind == 1:      # the convex test function: the whole record, to the end
+            assert r == int(z[nme + "/ret"]) and ev == rec.shape[0], (nme, r, int(z[nme + "/ret"]), ev, rec.shape[0])
+            assert (np.abs(tr - rec) / scale).max() < 1e-9, (nme, (np.abs(tr - rec) / scale).max())
+            assert np.abs(x - z[nme + "/x"]).max() < 1e-9 and abs(f - float(z[nme + "/f"])) <= 1e-12 * max(1.0, abs(f))
+        else:              # Rosenbrock amplifies the rounding of the dot products (numpy pairwise vs sequential): first 30 evaluations strictly, then the outcome
+            q = 30
+            assert (np.abs(tr[:q] - rec[:q]) / scale[:q]).max() < 1e-7, (nme, (np.abs(tr[:q] - rec[:q]) / scale[:q]).max())
+            assert r == int(z[nme + "/ret"]) and f < 1e-5 and abs(ev - rec.shape[0]) < 0.25 * rec.shape[0]
