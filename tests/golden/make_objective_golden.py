@@ -180,6 +180,38 @@ def objective(x, prob, cells, lam, mu, scale_cx, rho, scale_fx, use_scaling=True
     return jerk_cost + cost + tau_cost, (jerk_cost, cost, tau_cost), hx, gx, q3, Nxy
 
 
+def scaling(x0, prob, cells):
+    """initScaling (alm_traj_opt.cpp:349-661) by autograd: scale_fx = 1 / max(1, |grad of (jerk energy + surface-variation cost + rho_T T)|_inf)
+    with quirk Q3 in the tau entry, scale_cx[s, q] = 1 / max(1, |grad of the UNSCALED constraint q of sample s|_inf) -- one backward pass per
+    constraint, no hand-written chain rule"""
+    Nxy = prob["inner_xy"].shape[1] + 1
+    S = Nxy * (P["int_K"] + 1)
+    ones7, zeros = np.ones((S, 7)), np.zeros(S)
+    x = torch.tensor(x0, requires_grad=True)
+    _, parts, hx, gx, q3, _ = objective(x, prob, cells, zeros, np.zeros((S, 6)), ones7, 1.0, 1.0, use_scaling=False)
+    # with lambda = mu = 0, rho = 1 and unit scales: parts[0] = jerk energy, parts[2] = rho_T T; the surface-variation cost is recomputed below
+    tau = x0[0]
+    dT = (tau + 1.0) if tau > 0 else (1.0 - tau) / ((0.5 * tau - 1.0) * tau + 1.0) ** 2
+    x2 = torch.tensor(x0, requires_grad=True)
+    _, parts2, _, _, q3b, _ = objective(x2, prob, cells, zeros, np.zeros((S, 6)), ones7, 1e-300, 1.0, use_scaling=False)
+    # rho -> 0 removes the penalties of the (inactive, mu = 0) inequality terms and of the equality term: what is left of parts2[1] is the user cost
+    ffx = parts2[0] + parts2[1] + parts2[2]
+    ffx.backward()
+    gfx = x2.grad.detach().numpy().copy()
+    gfx[0] += float(q3b) / Nxy * dT
+    scale_fx = 1.0 / max(1.0, np.abs(gfx).max())
+    cons = torch.cat([hx[:, None], gx], dim=1)                    # (S, 7) unscaled constraint values at x
+    # (curvature and sigma rows carry the fixed cur_scale / sig_scale of the non-scaling mode above: divide them out)
+    fixed = torch.tensor([1.0, 1.0, 1.0, 1.0, 10.0, 1.0, 1000.0])
+    cons = cons / fixed
+    scale_cx = np.zeros((S, 7))
+    for si in range(S):
+        for q in range(7):
+            (gq,) = torch.autograd.grad(cons[si, q], x, retain_graph=True)
+            scale_cx[si, q] = 1.0 / max(1.0, float(gq.abs().max()))
+    return scale_fx, scale_cx
+
+
 def main():
     from uneven_planner_amd import scenes
     cells_np = scenes.analytic_cells()
@@ -210,6 +242,11 @@ def main():
                          init_xy=prob["init_xy"], end_xy=prob["end_xy"], inner_xy=prob["inner_xy"], init_yaw=prob["init_yaw"], end_yaw=prob["end_yaw"],
                          inner_yaw=prob["inner_yaw"], total_time=np.array(prob["total_time"])).items():
             out[name + "/" + k] = v
+        if name in ("rand0", "rand1"):              # initScaling at the unperturbed start (one backward pass per constraint: small problems only)
+            xs = np.concatenate([[tau0], prob["inner_xy"].T.ravel(), prob["inner_yaw"]])
+            sfx, scx = scaling(xs, prob, cells)
+            out[name + "/scaling_x"], out[name + "/scale_fx0"], out[name + "/scale_cx0"] = xs, np.array(sfx), scx
+            print(name, "initScaling: scale_fx", sfx, "scale_cx range", scx.min(), scx.max())
         print(name, "n", x0.size, "f", float(f.detach()), "parts", [float(p_.detach()) for p_ in parts], "|grad|", np.abs(g).max())
     np.savez_compressed(os.path.join(HERE, "objective_golden.npz"), **out)
 

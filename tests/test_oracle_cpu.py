@@ -307,3 +307,21 @@ def test_lbfgs_evaluates_the_same_points_as_the_independent_numpy_implementation
             q = 30
             assert (np.abs(tr[:q] - rec[:q]) / scale[:q]).max() < 1e-7, (nme, (np.abs(tr[:q] - rec[:q]) / scale[:q]).max())
             assert r == int(z[nme + "/ret"]) and f < 1e-5 and abs(ev - rec.shape[0]) < 0.25 * rec.shape[0]
+
+
+def test_init_scaling_matches_the_autograd_model(oracle, oracle_grid):
+    """initScaling (alm_traj_opt.cpp:349-661): scale_fx and all 7 S constraint scales against autograd of the independent forward model --
+    one backward pass per constraint function (tests/golden/make_objective_golden.py: scaling())"""
+    z = np.load(os.path.join(G, "objective_golden.npz"))
+    for nme in ("rand0", "rand1"):
+        g = lambda k: z[nme + "/" + k]
+        prob = dict(init_xy=g("init_xy"), end_xy=g("end_xy"), inner_xy=g("inner_xy"), init_yaw=g("init_yaw"), end_yaw=g("end_yaw"), inner_yaw=g("inner_yaw"),
+                    total_time=float(g("total_time")))
+        a = oracle.OracleALM(oracle_grid)
+        x0 = a.setup(prob)
+        assert np.abs(x0 - g("scaling_x")).max() < 1e-12
+        a.init_scaling(x0)
+        st = a.get_state()
+        assert abs(st["scale_fx"] - float(g("scale_fx0"))) / st["scale_fx"] < 1e-10, (st["scale_fx"], float(g("scale_fx0")))
+        d = np.abs(st["scale_cx"].reshape(-1, 7) - g("scale_cx0")) / g("scale_cx0")
+        assert d.max() < 1e-9, (nme, d.max(), np.unravel_index(d.argmax(), d.shape))
