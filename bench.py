@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--map-size", type=float, default=1000.0, help="km2 workload: side of the square map [m]")
     ap.add_argument("--tiled", action="store_true", help="km2 workload, N > 1: every rank holds only its x-slab of the grid plus a 20 m halo and solves the problems that "
                                                          "start in its slab (owner routing, SURVEY.md 8e row 3) instead of replicating the grid")
+    ap.add_argument("--fp32", action="store_true", help="fp32 arithmetic in the sample phase of the objective (uph_ctx_set_sample_precision(32); configs[4] \"fp32\"); "
+                                                        "the line then says dtype \"f32 samples / f64 solver\"")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = automatic: 128 for large batches)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="also time the CPU oracle with this many threads (one trajectory per thread; context only)")
     args = ap.parse_args()
@@ -119,6 +121,8 @@ def main():
     opt = U.ALMTrajOpt(m)
     if args.lanes:
         opt.set_lanes(args.lanes)
+    if args.fp32:
+        opt.set_sample_precision(32)
     opt.upload(probs)          # inputs resident in HBM from here on
 
     def barrier():
@@ -208,7 +212,7 @@ def main():
         res = {
             "metric": "MINCO traj-opts/sec (batch)", "value": value, "unit": "traj-opts/s", "n_gpus": world, "steps": K,
             "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if km2 else "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 samples / f64 solver" if args.fp32 else "f64", "data": "synthetic",
             "config": {"workload": ("configs[4]: analytic fractal terrain %.0f m x %.0f m (fBm H 0.8, seed 7), fp32 cell storage with fp64 arithmetic, one batch of %d "
                                     "local-goal (4-14 m) full ALM solves split over the GPUs, run_hill.yaml params" % (args.map_size, args.map_size, total_batch)) if km2 else
                                    ("hill scene (synthetic hill cloud, map built on device), batch of %d random start/goal "

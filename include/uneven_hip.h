@@ -225,6 +225,10 @@ void uph_ctx_destroy(uph_ctx* c);
 int uph_ctx_set_lanes(uph_ctx* c, int32_t lanes);
 /* experiment knob: 2 = register-capped kernel build (two waves per SIMD), 1 = uncapped, 0 = choose from the batch size */
 int uph_ctx_set_wps(uph_ctx* c, int32_t wps);
+/* BASELINE.json configs[4] "fp32": bits = 32 makes the sample phase of the objective (polynomial evaluation, terrain lookup, penalties and
+ * their chain rule: alm_traj_opt.cpp:716-988) compute in fp32 -- MINCO, the gradient reduction, L-BFGS and ALM stay fp64.  The reference is
+ * double-only: results are then NOT comparable at 1e-9, only through cost / feasibility statistics (tests/test_gpu_km2.py).  64 = default. */
+int uph_ctx_set_sample_precision(uph_ctx* c, int32_t bits);
 int uph_ctx_set_rho(uph_ctx* c, double rho);
 int uph_ctx_get_rho(uph_ctx* c, double* rho);
 

@@ -170,3 +170,39 @@ def test_grid_beyond_4GiB_is_addressed_correctly(oracle):
     opt.set_rho(1.0)
     out = opt.optimize_batch(far)
     assert all(o["ret"] in (0, 2) for o in out) and np.mean([o["ret"] == 0 for o in out]) >= 0.5
+
+
+def test_fp32_sample_mode_tracks_the_fp64_path(small_maps):
+    """uph_ctx_set_sample_precision(32): the sample phase computes in fp32 (configs[4] "fp32").  The reference is double-only, so the
+    statement is relative to this library's own fp64 path on the same problems: one evaluation agrees to fp32 rounding (f 1e-6, gradient
+    1e-4), and whole solves agree in what they deliver -- convergence rate, feasibility of the converged ones, cost level"""
+    import uneven_planner_amd as U
+    from uneven_planner_amd import scenes
+    _, m32 = small_maps
+    nx, ny = int(m32.voxel_num[0]), int(m32.voxel_num[1])
+    probs = scenes.local_problems(512, seed0=6000, half=14.0, dmin=4.0, dmax=12.0, occ_r2=m32.occ_r2_buffer,
+                                  grid=(nx, ny, m32.xy_resolution, m32.map_origin[0], m32.map_origin[1]))
+    res = {}
+    for bits in (64, 32):
+        opt = U.ALMTrajOpt(m32)
+        opt.set_sample_precision(bits)
+        opt.upload(probs)
+        opt.init_scaling_batch()
+        f, g = opt.eval_batch(None)
+        opt.upload(probs)
+        opt.set_rho(1.0)
+        opt.solve()
+        res[bits] = (f, g, opt.download(), opt.getMaxVxAxAyCurAttSig())
+    f64, g64, o64, r64 = res[64]
+    f32, g32, o32, r32 = res[32]
+    assert (np.abs(f32 - f64) / np.abs(f64)).max() < 1e-5
+    gd = np.array([np.abs(a - b).max() / np.abs(b).max() for a, b in zip(g32, g64)])
+    assert np.median(gd) < 1e-5 and gd.max() < 1e-3, (np.median(gd), gd.max())
+    assert not np.array_equal(f32, f64)                                         # it IS another arithmetic
+    c64, c32 = np.array([o["ret"] == 0 for o in o64]), np.array([o["ret"] == 0 for o in o32])
+    assert abs(c64.mean() - c32.mean()) < 0.05 and all(o["ret"] in (0, 2) for o in o32)
+    assert np.all(np.abs(r32[c32, 0]) < 0.5 * 1.05) and np.all(r32[c32, 5] < 0.05 * 1.1)        # converged => within max_vel / max_sig
+    k64, k32 = np.array([o["cost"] for o in o64]), np.array([o["cost"] for o in o32])
+    assert abs(np.median(k32) - np.median(k64)) / np.median(k64) < 0.02
+    with pytest.raises(U._lib.UnevenHipError):
+        U.ALMTrajOpt(m32).set_sample_precision(16)

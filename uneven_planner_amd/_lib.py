@@ -89,6 +89,7 @@ SYMBOLS = {
     "uph_ctx_destroy": (None, [_VP]),
     "uph_ctx_set_lanes": (C.c_int, [_VP, _I32]),
     "uph_ctx_set_wps": (C.c_int, [_VP, _I32]),
+    "uph_ctx_set_sample_precision": (C.c_int, [_VP, _I32]),
     "uph_ctx_set_rho": (C.c_int, [_VP, C.c_double]),
     "uph_ctx_get_rho": (C.c_int, [_VP, DP]),
     "uph_ctx_set_trace": (C.c_int, [_VP, _I32]),

@@ -131,6 +131,10 @@ class ALMTrajOpt:
     def set_wps(self, wps):
         _lib.check(self.L.uph_ctx_set_wps(self.h, int(wps)), "uph_ctx_set_wps")
 
+    def set_sample_precision(self, bits):
+        """32: fp32 arithmetic in the sample phase of the objective (configs[4] "fp32"; no 1e-9 parity with the double-only reference); 64: default"""
+        _lib.check(self.L.uph_ctx_set_sample_precision(self.h, int(bits)), "uph_ctx_set_sample_precision")
+
     def set_rho(self, rho):
         _lib.check(self.L.uph_ctx_set_rho(self.h, float(rho)), "uph_ctx_set_rho")
 

@@ -44,7 +44,8 @@ namespace uph {
 #define UPH_SC_YB 10
 #endif
 
-template <class WG>
+// SR = real type of the sample-phase arithmetic: double (the reference's, default) or f32r (fp32 sample mode, uph_common.hpp)
+template <class WG, class SR = double>
 struct Solver {
     WG& wg;
     const GridDev& grid;
@@ -261,21 +262,24 @@ struct Solver {
     }
 
     // ------------------------------------------------------------------ per-sample kinematics + terrain
-    struct Kin {
-        double b0[6], b1[6], b2[6], b3[6];
-        double y0[6], y1[6], y2[6];
-        double pos[2], vel[2], acc[2], jer[2];
-        double yaw, dyaw, d2yaw, cyaw, syaw, v_norm, lon_acc, lat_acc, u, s1;
-        double tv[7], tg[7][3];
-        double vx, wz, ax, ay, curv_snorm, den, sq;
-        double yawn, cw, sw;                 // wrapped yaw and its cos / sin (uneven_map.h:329-330)
-        double zx, zy, gs[3], gzx[3], gzy[3]; // interpolated zb and the base gradients (penalty path)
+    template <class R>
+    struct KinT {
+        R b0[6], b1[6], b2[6], b3[6];
+        R y0[6], y1[6], y2[6];
+        R pos[2], vel[2], acc[2], jer[2];
+        R yaw, dyaw, d2yaw, cyaw, syaw, v_norm, lon_acc, lat_acc, u, s1;
+        R tv[7], tg[7][3];
+        R vx, wz, ax, ay, curv_snorm, den, sq;
+        R yawn, cw, sw;                 // wrapped yaw and its cos / sin (uneven_map.h:329-330)
+        R zx, zy, gs[3], gzx[3], gzy[3]; // interpolated zb and the base gradients (penalty path)
         int yaw_idx;
     };
+    typedef KinT<double> Kin;
     // penalty path: only (sigma, zb) and their gradients are gathered; the seven attitude terms follow from them here and their
     // gradients are never formed individually (sampleEval folds them into four scalar coefficients)
-    UPH_HD void terrainValuesOnly(Kin& S_) const {
-        double sg;
+    template <class R>
+    UPH_HD void terrainValuesOnly(KinT<R>& S_) const {
+        R sg;
 #if defined(__HIP_DEVICE_COMPILE__) && UPH_GRID_FROM_MEM
         // the grid descriptor through an opaque constant-address-space pointer: scalar loads issued here, nothing for the compiler to
         // keep live (and spill to VGPR lanes) across the solver's loops
@@ -288,25 +292,25 @@ struct Solver {
         for (int k = 0; k < NWORD; k++) w[k] = T[k];
         GridDev gl;
         __builtin_memcpy(&gl, w, sizeof(GridDev));
-        terrainBase(gl, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
+        terrainBase<R>(gl, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
 #else
-        terrainBase(grid, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
+        terrainBase<R>(grid, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
 #endif
-        const double zx = S_.zx, zy = S_.zy;
-        const double cc = sqrt(1.0 - zx * zx - zy * zy);                 // uneven_map.h:327-348
-        const double inv_c = 1.0 / cc;
-        const double t = S_.cw * zx + S_.sw * zy;
-        const double s = -(-S_.sw * zx + S_.cw * zy);
-        const double sq = sqrt(1.0 - t * t);
-        const double r = 1.0 / sq;
+        const R zx = S_.zx, zy = S_.zy;
+        const R cc = sqrt(1.0 - zx * zx - zy * zy);                 // uneven_map.h:327-348
+        const R inv_c = 1.0 / cc;
+        const R t = S_.cw * zx + S_.sw * zy;
+        const R s = -(-S_.sw * zx + S_.cw * zy);
+        const R sq = sqrt(1.0 - t * t);
+        const R r = 1.0 / sq;
         S_.sq = sq;
         S_.tv[0] = r; S_.tv[1] = -cc * t * r; S_.tv[2] = sq * inv_c; S_.tv[3] = s * r; S_.tv[4] = cc; S_.tv[5] = inv_c; S_.tv[6] = sg;
     }
-    template <bool WITH_GRADS = true>
-    UPH_HD void kin(int i, int j, Kin& S_) const {
-        const double s1 = bt[Nxy + 1 + j];                              // :713-714,987: the s1 += step accumulation (Q2), tabulated by generate()
+    template <bool WITH_GRADS = true, class R = double>
+    UPH_HD void kin(int i, int j, KinT<R>& S_) const {
+        const R s1 = bt[Nxy + 1 + j];                              // :713-714,987: the s1 += step accumulation (Q2), tabulated by generate()
         S_.s1 = s1;
-        const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;   // :734-741
+        const R s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;   // :734-741
         S_.b0[0] = 1.0; S_.b0[1] = s1; S_.b0[2] = s2; S_.b0[3] = s3; S_.b0[4] = s4; S_.b0[5] = s5;
         S_.b1[0] = 0.0; S_.b1[1] = 1.0; S_.b1[2] = 2.0 * s1; S_.b1[3] = 3.0 * s2; S_.b1[4] = 4.0 * s3; S_.b1[5] = 5.0 * s4;
         S_.b2[0] = 0.0; S_.b2[1] = 0.0; S_.b2[2] = 2.0; S_.b2[3] = 6.0 * s1; S_.b2[4] = 12.0 * s2; S_.b2[5] = 20.0 * s3;
@@ -314,51 +318,51 @@ struct Solver {
         const double* c = cxy + 12 * i;
 #pragma unroll
         for (int dd = 0; dd < 2; dd++) {                                // :742-745
-            double a = 0, b = 0, cc = 0, e = 0;
+            R a = R(0.0), b = R(0.0), cc = R(0.0), e = R(0.0);
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                double cv = c[k * 2 + dd];
+                const R cv = c[k * 2 + dd];
                 a += cv * S_.b0[k]; b += cv * S_.b1[k]; cc += cv * S_.b2[k]; e += cv * S_.b3[k];
             }
             S_.pos[dd] = a; S_.vel[dd] = b; S_.acc[dd] = cc; S_.jer[dd] = e;
         }
-        const double now_time = s1 + bt[i];                             // :748-753
-        int yi = (int)divR(now_time, Tyaw, ec_iTyaw);
+        const R now_time = s1 + bt[i];                             // :748-753
+        int yi = toInt<R>(divR(now_time, R(Tyaw), R(ec_iTyaw)));
         if (yi >= Nyaw) yi = Nyaw - 1;
         if (yi < 0) yi = 0;                                             // (cannot happen for finite positive times; keeps indices in range)
         S_.yaw_idx = yi;
-        const double u1 = now_time - yi * Tyaw;
+        const R u1 = now_time - yi * Tyaw;
         S_.u = u1;
-        const double u2 = u1 * u1, u3 = u2 * u1, u4 = u2 * u2, u5 = u4 * u1;
+        const R u2 = u1 * u1, u3 = u2 * u1, u4 = u2 * u2, u5 = u4 * u1;
         S_.y0[0] = 1.0; S_.y0[1] = u1; S_.y0[2] = u2; S_.y0[3] = u3; S_.y0[4] = u4; S_.y0[5] = u5;
         S_.y1[0] = 0.0; S_.y1[1] = 1.0; S_.y1[2] = 2.0 * u1; S_.y1[3] = 3.0 * u2; S_.y1[4] = 4.0 * u3; S_.y1[5] = 5.0 * u4;
         S_.y2[0] = 0.0; S_.y2[1] = 0.0; S_.y2[2] = 2.0; S_.y2[3] = 6.0 * u1; S_.y2[4] = 12.0 * u2; S_.y2[5] = 20.0 * u3;
         const double* cy = cyaw + 6 * yi;
-        double yaw = 0, dyaw = 0, d2yaw = 0;                            // :762-764
+        R yaw = R(0.0), dyaw = R(0.0), d2yaw = R(0.0);                            // :762-764
 #pragma unroll
-        for (int k = 0; k < 6; k++) { yaw += cy[k] * S_.y0[k]; dyaw += cy[k] * S_.y1[k]; d2yaw += cy[k] * S_.y2[k]; }
+        for (int k = 0; k < 6; k++) { const R cv = cy[k]; yaw += cv * S_.y0[k]; dyaw += cv * S_.y1[k]; d2yaw += cv * S_.y2[k]; }
         S_.yaw = yaw; S_.dyaw = dyaw; S_.d2yaw = d2yaw;
-        const double yawn = normSO2(yaw);                               // :767-770
+        const R yawn = normSO2(yaw);                               // :767-770
         sincosFast(yaw, S_.syaw, S_.cyaw);                              // one argument reduction for both
         // cos / sin of the WRAPPED yaw (uneven_map.h:329-330): yawn = yaw - 2 pi k differs from yaw by a rounding of ~1e-16 |yaw|,
         // so the same pair serves (the reference evaluates cos / sin a second time on the wrapped value)
-        const double cw = S_.cyaw, sw = S_.syaw;
+        const R cw = S_.cyaw, sw = S_.syaw;
         S_.v_norm = sqrt(S_.vel[0] * S_.vel[0] + S_.vel[1] * S_.vel[1]);   // :771-775
         S_.lon_acc = S_.acc[0] * S_.cyaw + S_.acc[1] * S_.syaw;
         S_.lat_acc = S_.acc[0] * (-S_.syaw) + S_.acc[1] * S_.cyaw;
         S_.yawn = yawn; S_.cw = cw; S_.sw = sw;
-        if (WITH_GRADS) terrainAllWithGrad(grid, S_.pos[0], S_.pos[1], yawn, cw, sw, S_.tv, S_.tg);   // :778
-        else terrainValuesOnly(S_);
+        if constexpr (WITH_GRADS) terrainAllWithGrad(grid, S_.pos[0], S_.pos[1], yawn, cw, sw, S_.tv, S_.tg);   // :778  (initScaling: R = double)
+        else terrainValuesOnly<R>(S_);
         S_.vx = S_.v_norm * S_.tv[0];                                   // :813-817
         S_.wz = dyaw * S_.tv[5];
         S_.ax = S_.lon_acc * S_.tv[0] + grid.gravity * S_.tv[1];
         S_.ay = S_.lat_acc * S_.tv[2] + grid.gravity * S_.tv[3];
         S_.den = 1.0 / (S_.vx * S_.vx + delta_sigl);
-        S_.curv_snorm = divR(S_.wz * S_.wz, S_.vx * S_.vx + delta_sigl, S_.den);
+        S_.curv_snorm = divR(S_.wz * S_.wz, R(S_.vx * S_.vx + delta_sigl), S_.den);
     }
 
-    UPH_HD double augCost(double h, double lm) const { return h * (lm + 0.5 * rho * h); }   // alm_traj_opt.h:153-163
-    UPH_HD double augGrad(double h, double lm) const { return rho * h + lm; }
+    template <class R> UPH_HD R augCost(R h, R lm) const { return h * (lm + 0.5 * rho * h); }   // alm_traj_opt.h:153-163
+    template <class R> UPH_HD R augGrad(R h, R lm) const { return rho * h + lm; }
 
     // What the sample leaves for the per-piece reduction (alm_traj_opt.cpp:969-979):
     //   rec[0..5]  = grad_p, grad_v, grad_a (2 each): scatterChunk applies the basis weights beta0/1/2 of the sample's in-piece time
@@ -366,11 +370,12 @@ struct Solver {
     //                tabulated once per evaluation (wtab, written by the 17 samples of piece 0)
     //   rec[6+k]   = beta0_k(u) grad_yaw + beta1_k(u) grad_dyaw   -> gdCyaw block of its yaw piece (grad_d2yaw == 0, Q8)
     //   rtag       = that yaw piece (int32)
-    UPH_HD void putRec(int slot, int i, int j, const double gp_[2], const double gv_[2], const double ga_[2], double gyaw, double gdyaw, const Kin& k) {
+    template <class R>
+    UPH_HD void putRec(int slot, int i, int j, const R gp_[2], const R gv_[2], const R ga_[2], R gyaw, R gdyaw, const KinT<R>& k) {
         rec[0 * CHP + slot] = gp_[0]; rec[1 * CHP + slot] = gp_[1];
         rec[2 * CHP + slot] = gv_[0]; rec[3 * CHP + slot] = gv_[1];
         rec[4 * CHP + slot] = ga_[0]; rec[5 * CHP + slot] = ga_[1];
-        const double u1 = k.u, u2 = u1 * u1, u3 = u2 * u1, u4 = u2 * u2, u5 = u4 * u1;
+        const R u1 = k.u, u2 = u1 * u1, u3 = u2 * u1, u4 = u2 * u2, u5 = u4 * u1;
         rec[6 * CHP + slot] = gyaw;
         rec[7 * CHP + slot] = (u1 * gyaw + gdyaw);
         rec[8 * CHP + slot] = (u2 * gyaw + 2.0 * u1 * gdyaw);
@@ -380,7 +385,7 @@ struct Solver {
         rtag[slot] = k.yaw_idx;
         if (i == 0) {                                    // the powers behind beta0/1/2 of alm_traj_opt.cpp:738-740 at s1(j) (rebuilt from s1: not kept live across the sample)
             double* w = wtab + 6 * j;
-            const double s1 = k.s1, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+            const R s1 = k.s1, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
             w[0] = 1.0; w[1] = s1; w[2] = s2; w[3] = s3; w[4] = s4; w[5] = s5;
         }
     }
@@ -389,19 +394,19 @@ struct Solver {
     // The residuals hx / gx (alm_traj_opt.cpp:835, 846 ...) are consumed only by the dual update after an L-BFGS pass, so the
     // evaluations of the pass do not store them (7 stores per sample and their drain at the chunk barrier): RES_ONLY = true is the
     // same code up to the residuals, run once over the last evaluated trajectory when the pass ends (refreshResiduals).
-    template <bool RES_ONLY>
+    template <bool RES_ONLY, class R = double>
     UPH_HD void sampleEval(int s, int slot, double* acc) {
         const int i = divSmall(s, K + 1, inv_k1), j = s - i * (K + 1);
         // all 14 dual / scale operands are fetched up front: they are independent of the kinematics, their HBM/L2 latency overlaps
         // the polynomial evaluation and the terrain gather instead of serialising round trips
-        double dl[7], sc7[7];
+        R dl[7], sc7[7];
 #pragma unroll
-        for (int q = 0; q < 7; q++) { dl[q] = RES_ONLY ? 0.0 : dual[q * S + s]; sc7[q] = scl[q * S + s]; }
-        Kin k;
-        kin<false>(i, j, k);
-        const double icvx = k.tv[0], icvy = k.tv[2], cos_xi = k.tv[4], icxi = k.tv[5], sigma = k.tv[6];
-        const double vx = k.vx, wz = k.wz, ax = k.ax, ay = k.ay, curv = k.curv_snorm;
-        const double nh0 = k.syaw, nh1 = -k.cyaw;
+        for (int q = 0; q < 7; q++) { dl[q] = R(RES_ONLY ? 0.0 : dual[q * S + s]); sc7[q] = R(scl[q * S + s]); }
+        KinT<R> k;
+        kin<false, R>(i, j, k);
+        const R icvx = k.tv[0], icvy = k.tv[2], cos_xi = k.tv[4], icxi = k.tv[5], sigma = k.tv[6];
+        const R vx = k.vx, wz = k.wz, ax = k.ax, ay = k.ay, curv = k.curv_snorm;
+        const R nh0 = k.syaw, nh1 = -k.cyaw;
         // residuals: non-holonomic :830-835, then g1..g6 :841-946 (Q6: without use_scaling only curvature and sigma take fixed scales)
 #if defined(__HIP_DEVICE_COMPILE__) && UPH_GRID_FROM_MEM
         // the limits through an opaque constant-address-space pointer (scalar loads here instead of SGPRs held, and spilled, across the solve)
@@ -417,90 +422,90 @@ struct Solver {
 #else
         const OptParams& Pm = P;
 #endif
-        const double h = (k.vel[0] * nh0 + k.vel[1] * nh1) * sc7[0];
-        const double g1 = (vx * vx - Pm.max_vel2) * sc7[1];
-        const double g2 = (ax * ax - Pm.max_acc_lon2) * sc7[2];
-        const double g3 = (ay * ay - Pm.max_acc_lat2) * sc7[3];
-        const double sc4 = Pm.use_scaling ? sc7[4] : cur_scale;
-        const double g4 = (curv - Pm.max_kap2) * sc4;
-        const double g5 = (Pm.min_cxi - cos_xi) * sc7[5];
-        const double sc6 = Pm.use_scaling ? sc7[6] : sig_scale;
-        const double g6 = (sigma - Pm.max_sig) * sc6;
+        const R h = (k.vel[0] * nh0 + k.vel[1] * nh1) * sc7[0];
+        const R g1 = (vx * vx - Pm.max_vel2) * sc7[1];
+        const R g2 = (ax * ax - Pm.max_acc_lon2) * sc7[2];
+        const R g3 = (ay * ay - Pm.max_acc_lat2) * sc7[3];
+        const R sc4 = Pm.use_scaling ? sc7[4] : R(cur_scale);
+        const R g4 = (curv - Pm.max_kap2) * sc4;
+        const R g5 = (Pm.min_cxi - cos_xi) * sc7[5];
+        const R sc6 = Pm.use_scaling ? sc7[6] : R(sig_scale);
+        const R g6 = (sigma - Pm.max_sig) * sc6;
         if (RES_ONLY) {
             res[0 * S + s] = h; res[1 * S + s] = g1; res[2 * S + s] = g2; res[3 * S + s] = g3;
             res[4 * S + s] = g4; res[5 * S + s] = g5; res[6 * S + s] = g6;
             return;
         }
-        const double alpha = ec_invK * j;                               // :718  (1.0 / K * j)
-        const double gravity = grid.gravity;
-        double grad_p[2] = {0, 0}, grad_v[2] = {0, 0}, grad_a[2] = {0, 0};
-        double grad_yaw = 0.0, grad_dyaw = 0.0, grad_vx2 = 0.0, grad_wz = 0.0, grad_ax = 0.0, grad_ay = 0.0;
-        double grad_se2[3] = {0, 0, 0};
+        const R alpha = ec_invK * j;                               // :718  (1.0 / K * j)
+        const R gravity = grid.gravity;
+        R grad_p[2] = {R(0.0), R(0.0)}, grad_v[2] = {R(0.0), R(0.0)}, grad_a[2] = {R(0.0), R(0.0)};
+        R grad_yaw = R(0.0), grad_dyaw = R(0.0), grad_vx2 = R(0.0), grad_wz = R(0.0), grad_ax = R(0.0), grad_ay = R(0.0);
+        R grad_se2[3] = {R(0.0), R(0.0), R(0.0)};
         // weights of the gradients of the seven terrain terms (invCosVphix, sinPhix, invCosVphiy, sinPhiy, cosXi, invCosXi, sigma):
         // grad_se2 = sum_q W[q] * grad(term_q); the sum is folded onto the three base gradients at the end
-        double W[7] = {0, 0, 0, 0, 0, 0, 0};
-        double aug_grad, cost = 0.0;
-        const double irho = ec_irho;
+        R W[7] = {R(0.0), R(0.0), R(0.0), R(0.0), R(0.0), R(0.0), R(0.0)};
+        R aug_grad, cost = R(0.0);
+        const R irho = ec_irho;
         // user-defined cost: surface variation                          :819-827
-        const double omega = (j == 0 || j == K) ? ec_omega_h : ec_omega;     // (0.5 *) rho_ter * step * scale_fx
-        const double user_cost = omega * sigma * sigma;
+        const R omega = R((j == 0 || j == K) ? ec_omega_h : ec_omega);     // (0.5 *) rho_ter * step * scale_fx
+        const R user_cost = omega * sigma * sigma;
         cost += user_cost;
         W[6] += omega * sigma * 2.0;
-        double tx = user_cost / K;                                      // Q3
+        R tx = user_cost / K;                                      // Q3
         // non-holonomic                                                 :829-838
         {
-            const double lm = dl[0], sc = sc7[0];
-            cost += augCost(h, lm);
-            const double ng = augGrad(h, lm) * sc;
+            const R lm = dl[0], sc = sc7[0];
+            cost += augCost<R>(h, lm);
+            const R ng = augGrad<R>(h, lm) * sc;
             grad_v[0] += ng * nh0; grad_v[1] += ng * nh1;
             grad_yaw += ng * (k.vel[0] * k.cyaw + k.vel[1] * k.syaw);
         }
         // longitude velocity                                            :840-854
         {
-            const double mu = dl[1], sc = sc7[1], gv = g1;
-            if (rho * gv + mu > 0) { cost += augCost(gv, mu); aug_grad = augGrad(gv, mu) * sc; grad_vx2 += aug_grad; }
-            else cost += divR(-0.5 * mu * mu, rho, irho);
+            const R mu = dl[1], sc = sc7[1], gv = g1;
+            if (rho * gv + mu > 0) { cost += augCost<R>(gv, mu); aug_grad = augGrad<R>(gv, mu) * sc; grad_vx2 += aug_grad; }
+            else cost += divR(R(-0.5 * mu * mu), R(rho), irho);
         }
         // longitude acceleration                                        :856-870
         {
-            const double mu = dl[2], sc = sc7[2], gv = g2;
-            if (rho * gv + mu > 0) { cost += augCost(gv, mu); aug_grad = augGrad(gv, mu) * sc; grad_ax += aug_grad * 2.0 * ax; }
-            else cost += divR(-0.5 * mu * mu, rho, irho);
+            const R mu = dl[2], sc = sc7[2], gv = g2;
+            if (rho * gv + mu > 0) { cost += augCost<R>(gv, mu); aug_grad = augGrad<R>(gv, mu) * sc; grad_ax += aug_grad * 2.0 * ax; }
+            else cost += divR(R(-0.5 * mu * mu), R(rho), irho);
         }
         // latitude acceleration                                         :872-886
         {
-            const double mu = dl[3], sc = sc7[3], gv = g3;
-            if (rho * gv + mu > 0) { cost += augCost(gv, mu); aug_grad = augGrad(gv, mu) * sc; grad_ay += aug_grad * 2.0 * ay; }
-            else cost += divR(-0.5 * mu * mu, rho, irho);
+            const R mu = dl[3], sc = sc7[3], gv = g3;
+            if (rho * gv + mu > 0) { cost += augCost<R>(gv, mu); aug_grad = augGrad<R>(gv, mu) * sc; grad_ay += aug_grad * 2.0 * ay; }
+            else cost += divR(R(-0.5 * mu * mu), R(rho), irho);
         }
         // curvature                                                     :888-910  (Q6)
         {
-            const double mu = dl[4], sc = sc4, gv = g4;
+            const R mu = dl[4], sc = sc4, gv = g4;
             if (rho * gv + mu > 0) {
-                const double den = k.den;
-                cost += augCost(gv, mu);
-                aug_grad = augGrad(gv, mu) * sc;
+                const R den = k.den;
+                cost += augCost<R>(gv, mu);
+                aug_grad = augGrad<R>(gv, mu) * sc;
                 grad_wz += aug_grad * den * 2.0 * wz;
                 grad_vx2 -= aug_grad * curv * den;
-            } else cost += divR(-0.5 * mu * mu, rho, irho);
+            } else cost += divR(R(-0.5 * mu * mu), R(rho), irho);
         }
         // attitude                                                      :912-925
         {
-            const double mu = dl[5], sc = sc7[5], gv = g5;
+            const R mu = dl[5], sc = sc7[5], gv = g5;
             if (rho * gv + mu > 0) {
-                cost += augCost(gv, mu);
-                const double ag = augGrad(gv, mu);
+                cost += augCost<R>(gv, mu);
+                const R ag = augGrad<R>(gv, mu);
                 W[4] -= ag * sc;
-            } else cost += divR(-0.5 * mu * mu, rho, irho);
+            } else cost += divR(R(-0.5 * mu * mu), R(rho), irho);
         }
         // surface variation                                             :927-946  (Q6)
         {
-            const double mu = dl[6], sc = sc6, gv = g6;
+            const R mu = dl[6], sc = sc6, gv = g6;
             if (rho * gv + mu > 0) {
-                cost += augCost(gv, mu);
-                const double ag = augGrad(gv, mu);
+                cost += augCost<R>(gv, mu);
+                const R ag = augGrad<R>(gv, mu);
                 W[6] += ag * sc;
-            } else cost += divR(-0.5 * mu * mu, rho, irho);
+            } else cost += divR(R(-0.5 * mu * mu), R(rho), irho);
         }
         // process with vx, wz, ax                                       :948-964
 #pragma unroll
@@ -517,15 +522,15 @@ struct Solver {
         {
             // grad(term_q) in terms of dt = grad(t), ds = grad(s), gc = grad(c), gs = grad(sigma)  (uneven_map.h:338-355):
             //   g0 = t r^3 dt   g1 = -(t r gc + r^3 c dt)   g2 = -(t r dt / c + sq gc / c^2)   g3 = r ds + t r^3 s dt   g4 = gc   g5 = -gc / c^2   g6 = gs
-            const double cc = k.tv[4], inv_c = k.tv[5], r = k.tv[0];
-            const double t = k.cw * k.zx + k.sw * k.zy, s_ = -(-k.sw * k.zx + k.cw * k.zy);
-            const double sq = k.sq, r3 = r * r * r;
-            const double Cdt = W[0] * t * r3 - W[1] * r3 * cc - W[2] * inv_c * t * r + W[3] * t * r3 * s_;
-            const double Cgc = -W[1] * t * r - W[2] * inv_c * inv_c * sq + W[4] - W[5] * inv_c * inv_c;
-            const double Cds = W[3] * r;
+            const R cc = k.tv[4], inv_c = k.tv[5], r = k.tv[0];
+            const R t = k.cw * k.zx + k.sw * k.zy, s_ = -(-k.sw * k.zx + k.cw * k.zy);
+            const R sq = k.sq, r3 = r * r * r;
+            const R Cdt = W[0] * t * r3 - W[1] * r3 * cc - W[2] * inv_c * t * r + W[3] * t * r3 * s_;
+            const R Cgc = -W[1] * t * r - W[2] * inv_c * inv_c * sq + W[4] - W[5] * inv_c * inv_c;
+            const R Cds = W[3] * r;
             // dt = gzx cw + gzy sw (yaw: - s),  ds = gzx sw - gzy cw (yaw: + t),  gc = -(gzx zx + gzy zy) / c
-            const double ax_ = Cdt * k.cw + Cds * k.sw - Cgc * k.zx * inv_c;      // coefficient of grad(zb.x)
-            const double ay_ = Cdt * k.sw - Cds * k.cw - Cgc * k.zy * inv_c;      // coefficient of grad(zb.y)
+            const R ax_ = Cdt * k.cw + Cds * k.sw - Cgc * k.zx * inv_c;      // coefficient of grad(zb.x)
+            const R ay_ = Cdt * k.sw - Cds * k.cw - Cgc * k.zy * inv_c;      // coefficient of grad(zb.y)
 #pragma unroll
             for (int q = 0; q < 3; q++) grad_se2[q] = ax_ * k.gzx[q] + ay_ * k.gzy[q] + W[6] * k.gs[q];
             grad_se2[2] += -Cdt * s_ + Cds * t;
@@ -533,10 +538,10 @@ struct Solver {
         grad_p[0] += grad_se2[0]; grad_p[1] += grad_se2[1];
         grad_yaw += grad_se2[2];
         // scatter terms (:966-985): the C-blocks are reduced per piece in scatter(); the T parts are summed here
-        putRec(slot, i, j, grad_p, grad_v, grad_a, grad_yaw, grad_dyaw, k);
+        putRec<R>(slot, i, j, grad_p, grad_v, grad_a, grad_yaw, grad_dyaw, k);
         tx += ((grad_p[0] * k.vel[0] + grad_p[1] * k.vel[1]) + (grad_v[0] * k.acc[0] + grad_v[1] * k.acc[1]) +
                (grad_a[0] * k.jer[0] + grad_a[1] * k.jer[1])) * alpha;
-        const double yawdot = (grad_yaw * k.dyaw + grad_dyaw * k.d2yaw);
+        const R yawdot = (grad_yaw * k.dyaw + grad_dyaw * k.d2yaw);
         tx += yawdot * (alpha + i);
         acc[0] += cost;
         acc[1] += tx;
@@ -794,7 +799,7 @@ struct Solver {
             const int cnt = S - s0 < CH ? S - s0 : CH;
             double part[3];
             t0 = wg.clock();
-            wg.template sum<3>(cnt, part, [&](int t, double* acc) { sampleEval<false>(s0 + t, t, acc); });
+            wg.template sum<3>(cnt, part, [&](int t, double* acc) { sampleEval<false, SR>(s0 + t, t, acc); });
             t1 = wg.clock(); cyc[1] += t1 - t0;
             sm[0] += part[0]; sm[1] += part[1]; sm[2] += part[2];
             scatterChunk(s0, cnt);

@@ -8,37 +8,42 @@
 
 namespace uph {
 
-struct Corners {
-    double dx, dy, dyaw;       // fractional offsets diff[0..2]
+template <class R>
+struct CornersT {
+    R dx, dy, dyaw;            // fractional offsets diff[0..2]
     int64_t a[2][2];           // address of (x,y) corner at yaw index w0
     int w0, w1;                // the two yaw bins
     bool inmap;
 };
+typedef CornersT<double> Corners;
 
-UPH_HD bool isInMap(const GridDev& g, double x, double y, double yaw) {     // uneven_map.h:437-454
+// R = double (the reference's arithmetic) or f32r (fp32 sample mode): the same code, see uph_common.hpp
+template <class R>
+UPH_HD bool isInMap(const GridDev& g, R x, R y, R yaw) {     // uneven_map.h:437-454
     if (x < g.lo[0] || y < g.lo[1] || yaw < g.lo[2]) return false;      // lo = minb + 1e-4, hi = maxb - 1e-4
     if (x > g.hi[0] || y > g.hi[1] || yaw > g.hi[2]) return false;
     return true;
 }
 
-UPH_HD void locate(const GridDev& g, double x, double y, double yaw, Corners& c) {
-    c.inmap = isInMap(g, x, y, yaw);
+template <class R>
+UPH_HD void locate(const GridDev& g, R x, R y, R yaw, CornersT<R>& c) {
+    c.inmap = isInMap<R>(g, x, y, yaw);
     if (!c.inmap) return;
     // uneven_map.h:268-284
-    double xm = x - g.half_xy, ym = y - g.half_xy;
-    double wm = normSO2(yaw - g.half_yaw);
+    R xm = x - g.half_xy, ym = y - g.half_xy;
+    R wm = normSO2(R(yaw - g.half_yaw));
     int ix = (int)floor((xm - g.origin[0]) * g.xy_inv);
     int iy = (int)floor((ym - g.origin[1]) * g.xy_inv);
     int iw = (int)floor((wm - g.origin[2]) * g.yaw_inv);
-    double cx = (ix + 0.5) * g.xy_res + g.origin[0];
-    double cy = (iy + 0.5) * g.xy_res + g.origin[1];
-    double cw = (iw + 0.5) * g.yaw_res + g.origin[2];
+    R cx = (ix + 0.5) * g.xy_res + g.origin[0];
+    R cy = (iy + 0.5) * g.xy_res + g.origin[1];
+    R cw = (iw + 0.5) * g.yaw_res + g.origin[2];
     c.dx = (x - cx) * g.xy_inv;
     c.dy = (y - cy) * g.xy_inv;
     // reference: atan2(sin(d), cos(d)) * yaw_inv  (:284).  d lies within one wrap of a yaw cell, so the exact range
     // reduction d - 2*pi*rint(d/(2*pi)) gives the same angle to ~1e-17 without three transcendentals.
     const double TWO_PI = 6.28318530717958647692;
-    double d = yaw - cw;
+    R d = yaw - cw;
     d = d - TWO_PI * rint(d / TWO_PI);
     c.dyaw = d * g.yaw_inv;
     // boundIndex :398-409: clamp x,y; wrap yaw modulo nyaw
@@ -69,8 +74,8 @@ UPH_HD void locate(const GridDev& g, double x, double y, double yaw, Corners& c)
 // One cell of the grid: {z, sigma, zb.x, zb.y} in the reference's RXS2 order (uneven_map.h:36-64, 427-435), stored either as four
 // doubles (32 bytes, two 16-byte loads; bit-faithful to the reference's map_buffer) or -- GridDev::cells32, BASELINE.json configs[4] --
 // as four floats (16 bytes, one load) widened to double on load: the arithmetic is fp64 either way.
-template <bool F32>
-UPH_HD void loadCell(const GridDev& g, int64_t idx, double f[4]) {      // f = {sigma, zb.x, zb.y, z}
+template <bool F32, class R>
+UPH_HD void loadCell(const GridDev& g, int64_t idx, R f[4]) {           // f = {sigma, zb.x, zb.y, z}
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef double dbl2_t __attribute__((ext_vector_type(2)));
     typedef float flt4_t __attribute__((ext_vector_type(4)));
@@ -84,7 +89,7 @@ UPH_HD void loadCell(const GridDev& g, int64_t idx, double f[4]) {      // f = {
 #endif
     if (F32) {
         const flt4_t v = ((cellp32)g.cells32)[idx];
-        f[3] = (double)v.x; f[0] = (double)v.y; f[1] = (double)v.z; f[2] = (double)v.w;
+        f[3] = toReal<R>(v.x); f[0] = toReal<R>(v.y); f[1] = toReal<R>(v.z); f[2] = toReal<R>(v.w);
     } else {
         const cellp p = (cellp)(g.cells + 4 * idx);
         const dbl2_t lo = p[0], hi = p[1];                  // (z, sigma), (zb.x, zb.y)
@@ -96,27 +101,27 @@ UPH_HD void loadCell(const GridDev& g, int64_t idx, double f[4]) {      // f = {
 // three at a located point: the operations and their order of uneven_map.h:297-311 (values alone: :192-198, the same expressions).
 // One yaw slice at a time -- the bilinear values and the x / y partial sums of a slice need only that slice's four cells, the two
 // slices meet in the last lerp -- so at most four cells are live at once (eight corners = 16 x 16-byte loads in the fp64 form, 8 in fp32).
-template <bool F32, bool GRAD, bool WITH_Z>
-UPH_HD void interpCells(const GridDev& g, const Corners& c, double val[4], double grd[3][3]) {
+template <bool F32, bool GRAD, bool WITH_Z, class R>
+UPH_HD void interpCells(const GridDev& g, const CornersT<R>& c, R val[4], R grd[3][3]) {
     constexpr int NF = WITH_Z ? 4 : 3;
-    const double dx = c.dx, dy = c.dy, dw = c.dyaw;
-    double v0[NF], v1[NF], gy0[3], gy1[3], gx[3];
+    const R dx = c.dx, dy = c.dy, dw = c.dyaw;
+    R v0[NF], v1[NF], gy0[3], gy1[3], gx[3];
 #pragma unroll
     for (int w = 0; w < 2; w++) {
         const int wi = w == 0 ? c.w0 : c.w1;
-        double f[2][2][4];                                  // (requesting all eight cells before the first use was measured: no gain under load, -0.7 %)
+        R f[2][2][4];                                  // (requesting all eight cells before the first use was measured: no gain under load, -0.7 %)
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++) loadCell<F32>(g, c.a[a][b] + wi, f[a][b]);
+            for (int b = 0; b < 2; b++) loadCell<F32, R>(g, c.a[a][b] + wi, f[a][b]);
 #pragma unroll
         for (int k = 0; k < NF; k++) {
-            const double vy0 = f[0][0][k] * (1 - dx) + f[1][0][k] * dx;       // v00 / v01 of uneven_map.h:297-300
-            const double vy1 = f[0][1][k] * (1 - dx) + f[1][1][k] * dx;       // v10 / v11
-            const double vv = vy0 * (1 - dy) + vy1 * dy;
+            const R vy0 = f[0][0][k] * (1 - dx) + f[1][0][k] * dx;       // v00 / v01 of uneven_map.h:297-300
+            const R vy1 = f[0][1][k] * (1 - dx) + f[1][1][k] * dx;       // v10 / v11
+            const R vv = vy0 * (1 - dy) + vy1 * dy;
             if (w == 0) v0[k] = vv; else v1[k] = vv;
             if (GRAD && k < 3) {
-                const double gxa = f[1][0][k] - f[0][0][k], gxb = f[1][1][k] - f[0][1][k];
+                const R gxa = f[1][0][k] - f[0][0][k], gxb = f[1][1][k] - f[0][1][k];
                 if (w == 0) { gy0[k] = vy1 - vy0; gx[k] = (1 - dw) * (1 - dy) * gxa; gx[k] += (1 - dw) * dy * gxb; }       // :305-308, same summation order
                 else { gy1[k] = vy1 - vy0; gx[k] += dw * (1 - dy) * gxa; gx[k] += dw * dy * gxb; }
             }
@@ -134,16 +139,17 @@ UPH_HD void interpCells(const GridDev& g, const Corners& c, double val[4], doubl
 }
 
 // Base quantities for the fused penalty kernel: interpolated (sigma, zb.x, zb.y) and their gradients w.r.t. (x, y, yaw).
-UPH_HD void terrainBase(const GridDev& g, double x, double y, double yaw, double& sg, double& zx, double& zy, double gs[3], double gzx[3], double gzy[3]) {
-    Corners c;
-    locate(g, x, y, yaw, c);
-    sg = zx = zy = 0.0;
+template <class R>
+UPH_HD void terrainBase(const GridDev& g, R x, R y, R yaw, R& sg, R& zx, R& zy, R gs[3], R gzx[3], R gzy[3]) {
+    CornersT<R> c;
+    locate<R>(g, x, y, yaw, c);
+    sg = R(0.0); zx = R(0.0); zy = R(0.0);
 #pragma unroll
-    for (int k = 0; k < 3; k++) { gs[k] = 0.0; gzx[k] = 0.0; gzy[k] = 0.0; }
+    for (int k = 0; k < 3; k++) { gs[k] = R(0.0); gzx[k] = R(0.0); gzy[k] = R(0.0); }
     if (!c.inmap) return;                                   // out of map: zeros (uneven_map.h:260-265)
-    double val[4], grd[3][3];
-    if (g.cells32) interpCells<true, true, false>(g, c, val, grd);
-    else interpCells<false, true, false>(g, c, val, grd);
+    R val[4], grd[3][3];
+    if (g.cells32) interpCells<true, true, false, R>(g, c, val, grd);
+    else interpCells<false, true, false, R>(g, c, val, grd);
     sg = val[0]; zx = val[1]; zy = val[2];
 #pragma unroll
     for (int k = 0; k < 3; k++) { gs[k] = grd[0][k]; gzx[k] = grd[1][k]; gzy[k] = grd[2][k]; }
@@ -154,8 +160,8 @@ UPH_HD void terrainValues(const GridDev& g, const Corners& c, double val[4]) {
     val[0] = val[1] = val[2] = val[3] = 0.0;
     if (!c.inmap) return;
     double grd[3][3];
-    if (g.cells32) interpCells<true, false, true>(g, c, val, grd);
-    else interpCells<false, false, true>(g, c, val, grd);
+    if (g.cells32) interpCells<true, false, true, double>(g, c, val, grd);
+    else interpCells<false, false, true, double>(g, c, val, grd);
 }
 
 // values / gradient rows: 0 invCosVphix, 1 sinPhix, 2 invCosVphiy, 3 sinPhiy, 4 cosXi, 5 invCosXi, 6 sigma

@@ -3,6 +3,8 @@
 // The map half (plane-fit build) lives in map_build.hip.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -447,14 +449,17 @@ struct DevWG {
 // MODE 0: one (or `repeat`) objective evaluation(s)   1: reset + initScaling   2: ALM / L-BFGS solve (repeat > 0: at most that many ALM passes)
 // 3: post-solve report   4: initScaling only (test hook, keeps the resident duals)   5: phase microbenchmark
 // 7: continue the L-BFGS loop from a host-given state (test hook; repeat = 2 * budget + finish_pass).  A compile-time MODE gives each phase its own register budget.
-template <int NT, int WPS, int MODE>
+// F32S: the sample phase of every objective evaluation computes in fp32 (Solver<WG, f32r>; BASELINE.json configs[4] "fp32"), everything else
+// -- MINCO, L-BFGS, ALM, the scatter and the accumulations -- stays fp64.  Own instantiations: the fp64 kernels are untouched by it.
+template <int NT, int WPS, int MODE, bool F32S = false>
 __global__ __launch_bounds__(NT, WPS) void uph_solver_kernel(GridDev grid, OptParams P, BatchDev bd, int repeat) {
     extern __shared__ double lds[];
     const int w = blockIdx.x;
     if (w >= bd.B) return;
     const int b = bd.order ? bd.order[w] : w;
     DevWG<NT> wg(lds);
-    Solver<DevWG<NT>> sol(wg, grid, P, bd, b, lds + DevWG<NT>::SCRATCH);
+    typedef typename std::conditional<F32S, f32r, double>::type SR;
+    Solver<DevWG<NT>, SR> sol(wg, grid, P, bd, b, lds + DevWG<NT>::SCRATCH);
     TrajState& st = bd.state[b];
     if (MODE == 0) sol.evalOnly(st, repeat);
     else if (MODE == 1) sol.prepare(st);
@@ -522,6 +527,7 @@ struct uph_ctx {
     int n_main = 0;                         // order[0, n_main) main class, order[n_main, B) oversize class
     std::vector<int> rejected;              // per problem: 0, or the status code that made it unsupported (solved as a placeholder, reported as UPH_RET_UNSUPPORTED)
     int n_rejected = 0;
+    bool sample_f32 = false;                // fp32 sample arithmetic (uph_ctx_set_sample_precision)
     hipStream_t stream2 = nullptr;
     hipEvent_t ev2 = nullptr;
     std::vector<size_t> fp_bytes;           // per-trajectory LDS footprint
@@ -630,7 +636,33 @@ static int launchSolver(uph_ctx* c, int mode, int repeat) {
         else if (mode == 5) UPH_LAUNCH(NTL, WPS, 5);                                                                                 \
         else UPH_LAUNCH(NTL, WPS, 4);                                                                                                \
     } while (0)
-    if (mode == 7) {
+#define UPH_LAUNCH32(NTL, WPS, MODE)                                                                                                   \
+    do {                                                                                                                             \
+        const size_t ldsmax = c->lds_big > c->lds_bytes ? c->lds_big : c->lds_bytes;                                                 \
+        HIPCHK(hipFuncSetAttribute((const void*)uph_solver_kernel<NTL, WPS, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax)); \
+        HIPCHK(hipEventRecord(c->ev0, c->stream));                                                                                   \
+        BatchDev bm = bd;                                                                                                            \
+        bm.B = c->n_main;                                                                                                            \
+        if (c->n_main < c->B) {                                                                                                      \
+            BatchDev bb = bd;                                                                                                        \
+            bb.B = c->B - c->n_main;                                                                                                 \
+            bb.order = bd.order + c->n_main;                                                                                         \
+            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev0, 0));                                                                       \
+            hipLaunchKernelGGL((uph_solver_kernel<NTL, WPS, MODE, true>), dim3(bb.B), dim3(NTL), c->lds_big, c->stream2, grid, c->P, bb, repeat); \
+            HIPCHK(hipEventRecord(c->ev2, c->stream2));                                                                              \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((uph_solver_kernel<NTL, WPS, MODE, true>), dim3(c->n_main), dim3(NTL), c->lds_bytes, c->stream, grid, c->P, bm, repeat); \
+        if (c->n_main < c->B) HIPCHK(hipStreamWaitEvent(c->stream, c->ev2, 0));                                                      \
+    } while (0)
+    if (c->sample_f32 && (mode == 0 || mode == 2) && (c->lanes == 128 || c->lanes == 256 || c->lanes == 512)) {
+        // fp32 sample arithmetic: evaluation and solve kernels of the three production lane counts (scaling / report / hooks stay fp64)
+        if (c->lanes == 128) { if (mode == 0) UPH_LAUNCH32(128, 2, 0); else UPH_LAUNCH32(128, 2, 2); }
+        else if (c->lanes == 512) { if (mode == 0) UPH_LAUNCH32(512, 1, 0); else UPH_LAUNCH32(512, 1, 2); }
+        else if (mode == 0) UPH_LAUNCH32(256, 1, 0);
+        else if (c->wps == 2 && c->lds_bytes <= 80 * 1024) UPH_LAUNCH32(256, 2, 2);
+        else UPH_LAUNCH32(256, 1, 2);
+    }
+    else if (mode == 7) {
         if (c->lanes == 128) UPH_LAUNCH(128, 2, 7);
         else if (c->lanes == 256) UPH_LAUNCH(256, 1, 7);
         else { setError("the L-BFGS resume hook is built for 128 and 256 lanes"); return UPH_ERR_INVALID; }
@@ -643,6 +675,7 @@ static int launchSolver(uph_ctx* c, int mode, int repeat) {
     else if (c->wps == 2 && mode == 5 && c->lds_bytes <= 80 * 1024) UPH_LAUNCH(256, 2, 5);
     else UPH_LAUNCH_MODE(256, 1);
 #undef UPH_LAUNCH_MODE
+#undef UPH_LAUNCH32
 #undef UPH_LAUNCH
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, c->stream));
@@ -724,6 +757,11 @@ int uph_ctx_set_lanes(uph_ctx* c, int32_t lanes) {
     return UPH_OK;
 }
 int uph_ctx_set_wps(uph_ctx* c, int32_t wps) { if (!c || wps < 0 || wps > 2) return UPH_ERR_INVALID; c->wps_forced = wps; return UPH_OK; }
+int uph_ctx_set_sample_precision(uph_ctx* c, int32_t bits) {
+    if (!c || (bits != 32 && bits != 64)) { setError("uph_ctx_set_sample_precision: 32 or 64"); return UPH_ERR_INVALID; }
+    c->sample_f32 = bits == 32;
+    return UPH_OK;
+}
 int uph_ctx_set_rho(uph_ctx* c, double rho) { if (!c) return UPH_ERR_INVALID; c->rho = rho; return UPH_OK; }
 int uph_ctx_get_rho(uph_ctx* c, double* rho) { if (!c || !rho) return UPH_ERR_INVALID; *rho = c->rho; return UPH_OK; }
 

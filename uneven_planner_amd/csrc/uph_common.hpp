@@ -245,6 +245,61 @@ UPH_HD void sincosFast(double x, double& sn, double& cs) {
     sn = (n & 2) ? -s0 : s0;
     cs = (n == 1 || n == 2) ? -c0 : c0;
 }
+// ---- fp32 sample arithmetic (BASELINE.json configs[4], "fp32"): a float that absorbs doubles.  The sample-phase code is written once,
+// templated on its real type R; with R = f32r every mixed expression (literal, double member, LDS operand) rounds to float and the
+// arithmetic issues as fp32 (twice the fp64 FMA rate on gfx950, single-instruction sqrt / rcp), with R = double nothing changes.
+struct f32r {
+    float v;
+    UPH_HD f32r() : v(0.f) {}
+    UPH_HD f32r(double d) : v((float)d) {}
+    UPH_HD f32r(float f, int) : v(f) {}
+    UPH_HD operator double() const { return (double)v; }
+};
+UPH_HD f32r mkf(float f) { return f32r(f, 0); }
+#define UPH_F32_BINOP(op)                                                                   \
+    UPH_HD f32r operator op(f32r a, f32r b) { return mkf(a.v op b.v); }                       \
+    UPH_HD f32r operator op(f32r a, double b) { return mkf(a.v op (float)b); }                \
+    UPH_HD f32r operator op(double a, f32r b) { return mkf((float)a op b.v); }                \
+    UPH_HD f32r operator op(f32r a, int b) { return mkf(a.v op (float)b); }                   \
+    UPH_HD f32r operator op(int a, f32r b) { return mkf((float)a op b.v); }
+UPH_F32_BINOP(+) UPH_F32_BINOP(-) UPH_F32_BINOP(*) UPH_F32_BINOP(/)
+#undef UPH_F32_BINOP
+#define UPH_F32_CMP(op)                                                                     \
+    UPH_HD bool operator op(f32r a, f32r b) { return a.v op b.v; }                            \
+    UPH_HD bool operator op(f32r a, double b) { return a.v op (float)b; }                     \
+    UPH_HD bool operator op(double a, f32r b) { return (float)a op b.v; }                     \
+    UPH_HD bool operator op(f32r a, int b) { return a.v op (float)b; }
+UPH_F32_CMP(<) UPH_F32_CMP(>) UPH_F32_CMP(<=) UPH_F32_CMP(>=)
+#undef UPH_F32_CMP
+UPH_HD f32r operator-(f32r a) { return mkf(-a.v); }
+UPH_HD f32r& operator+=(f32r& a, f32r b) { a.v += b.v; return a; }
+UPH_HD f32r& operator+=(f32r& a, double b) { a.v += (float)b; return a; }
+UPH_HD f32r& operator-=(f32r& a, f32r b) { a.v -= b.v; return a; }
+UPH_HD f32r& operator-=(f32r& a, double b) { a.v -= (float)b; return a; }
+UPH_HD f32r& operator*=(f32r& a, f32r b) { a.v *= b.v; return a; }
+UPH_HD double& operator+=(double& a, f32r b) { a += (double)b.v; return a; }      // accumulators stay double
+// (overloads in this namespace hide the global math functions for unqualified calls: re-export the double versions next to them)
+using ::sqrt; using ::fabs; using ::floor; using ::rint;
+UPH_HD f32r sqrt(f32r a) { return mkf(sqrtf(a.v)); }
+UPH_HD f32r fabs(f32r a) { return mkf(fabsf(a.v)); }
+UPH_HD f32r floor(f32r a) { return mkf(floorf(a.v)); }
+UPH_HD f32r rint(f32r a) { return mkf(rintf(a.v)); }
+UPH_HD f32r divR(f32r x, f32r, f32r r) { return mkf(x.v * r.v); }               // stored reciprocal: one multiply is within an fp32 ulp or two
+UPH_HD void sincosFast(f32r x, f32r& sn, f32r& cs) { float s_, c_; sincosf(x.v, &s_, &c_); sn = mkf(s_); cs = mkf(c_); }
+UPH_HD f32r normSO2(f32r yaw) {
+    const float PI = 3.14159265358979323846f;
+    float y = yaw.v;
+    for (int it = 0; it < 4096 && y < -PI; it++) y += 2 * PI;
+    for (int it = 0; it < 4096 && y > PI; it++) y -= 2 * PI;
+    return mkf(y);
+}
+template <class R> UPH_HD R toReal(float v);
+template <> UPH_HD double toReal<double>(float v) { return (double)v; }
+template <> UPH_HD f32r toReal<f32r>(float v) { return mkf(v); }
+template <class R> UPH_HD int toInt(R v);
+template <> UPH_HD int toInt<double>(double v) { return (int)v; }
+template <> UPH_HD int toInt<f32r>(f32r v) { return (int)v.v; }
+
 UPH_HD double logC2(double T) { return T > 1.0 ? (sqrt(2.0 * T - 1.0) - 1.0) : (1.0 - sqrt(2.0 / T - 1.0)); }
 UPH_HD double getTtoTauGrad(double tau) {
     if (tau > 0) return tau + 1.0;
