@@ -38,6 +38,8 @@ struct uph_map {
     double* d_c = nullptr;       // c_buffer (fp64 storage only)
     char* d_occ = nullptr;       // ncell
     char* d_occ2 = nullptr;      // nx * ny
+    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};      // query scratch (uphMapScratch)
+    size_t scratch_cap[4] = {0, 0, 0, 0};
     double last_build_ms = 0.0, last_query_ms = 0.0;
     int64_t last_cell_iters = 0, last_cloud = 0;
 };
@@ -46,6 +48,15 @@ UphDevTmp::~UphDevTmp() { if (p) hipFree(p); }
 UphEventTmp::~UphEventTmp() { if (e) hipEventDestroy((hipEvent_t)e); }
 
 int uphMapDevice(const uph_map* m) { return m->device; }
+void* uphMapScratch(uph_map* m, int slot, size_t bytes) {
+    if (bytes <= m->scratch_cap[slot]) return m->scratch[slot];
+    if (m->scratch[slot]) hipFree(m->scratch[slot]);
+    m->scratch[slot] = nullptr; m->scratch_cap[slot] = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(&m->scratch[slot], want) != hipSuccess) { setError("query scratch: hipMalloc failed"); return nullptr; }
+    m->scratch_cap[slot] = want;
+    return m->scratch[slot];
+}
 GridDev uphMapGrid(const uph_map* m) { return m->g; }
 
 #define HIPCHK(call)                                                                               \
@@ -555,6 +566,7 @@ void uph_map_destroy(uph_map* m) {
     if (!m) return;
     hipSetDevice(m->device);
     hipFree(m->d_cells); hipFree(m->d_cells32); hipFree(m->d_c); hipFree(m->d_occ); hipFree(m->d_occ2);
+    for (int k = 0; k < 4; k++) hipFree(m->scratch[k]);
     delete m;
 }
 
@@ -832,11 +844,10 @@ int64_t uph_map_filter_cloud(const float* xyz, int64_t n, float* out_xyz, int64_
 int uph_frontend_query(uph_map* m, const double* pos, int32_t n, double* sigma, int32_t* occ, int32_t* occ_xy) {
     if (!m || !pos || n <= 0 || (!sigma && !occ && !occ_xy)) { setError("uph_frontend_query: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
-    UphDevTmp tp, ts, t1, t2;
-    HIPCHK(hipMalloc(&tp.p, 8 * 3 * (size_t)n));
-    HIPCHK(hipMalloc(&ts.p, 8 * (size_t)n));
-    HIPCHK(hipMalloc(&t1.p, 4 * (size_t)n));
-    HIPCHK(hipMalloc(&t2.p, 4 * (size_t)n));
+    UphPtr tp, ts, t1, t2;
+    tp.p = uphMapScratch(m, 0, 8 * 3 * (size_t)n); ts.p = uphMapScratch(m, 1, 8 * (size_t)n);
+    t1.p = uphMapScratch(m, 2, 4 * (size_t)n); t2.p = uphMapScratch(m, 3, 4 * (size_t)n);
+    if (!tp.p || !ts.p || !t1.p || !t2.p) return UPH_ERR_HIP;
     HIPCHK(hipMemcpy(tp.p, pos, 8 * 3 * (size_t)n, hipMemcpyHostToDevice));
     UphEventTmp e0, e1;
     HIPCHK(hipEventCreate((hipEvent_t*)&e0.e)); HIPCHK(hipEventCreate((hipEvent_t*)&e1.e));
@@ -857,9 +868,9 @@ int uph_frontend_query(uph_map* m, const double* pos, int32_t n, double* sigma, 
 int uph_terrain_pose_query(uph_map* m, const double* pos, int32_t n, double* pose12) {
     if (!m || !pos || n <= 0 || !pose12) { setError("uph_terrain_pose_query: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
-    UphDevTmp tp, to;
-    HIPCHK(hipMalloc(&tp.p, 8 * 3 * (size_t)n));
-    HIPCHK(hipMalloc(&to.p, 8 * 12 * (size_t)n));
+    UphPtr tp, to;
+    tp.p = uphMapScratch(m, 0, 8 * 3 * (size_t)n); to.p = uphMapScratch(m, 1, 8 * 12 * (size_t)n);
+    if (!tp.p || !to.p) return UPH_ERR_HIP;
     HIPCHK(hipMemcpy(tp.p, pos, 8 * 3 * (size_t)n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(uph_pose_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, m->g, tp.as<double>(), n, to.as<double>());
     HIPCHK(hipGetLastError());

@@ -1197,10 +1197,9 @@ int uph_batch_get_lbfgs_state(uph_ctx* c, double* g, double* d, double* pf, doub
 int uph_terrain_query(uph_map* m, const double* pos, int32_t n, double* values7, double* grads21) {
     if (!m || !pos || n <= 0 || !values7 || !grads21) { setError("uph_terrain_query: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(uphMapDevice(m)));
-    UphDevTmp tp, tv, tg;
-    HIPCHK(hipMalloc(&tp.p, 8 * 3 * (size_t)n));
-    HIPCHK(hipMalloc(&tv.p, 8 * 7 * (size_t)n));
-    HIPCHK(hipMalloc(&tg.p, 8 * 21 * (size_t)n));
+    UphPtr tp, tv, tg;
+    tp.p = uphMapScratch(m, 0, 8 * 3 * (size_t)n); tv.p = uphMapScratch(m, 1, 8 * 7 * (size_t)n); tg.p = uphMapScratch(m, 2, 8 * 21 * (size_t)n);
+    if (!tp.p || !tv.p || !tg.p) return UPH_ERR_HIP;
     HIPCHK(hipMemcpy(tp.p, pos, 8 * 3 * (size_t)n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(uph_terrain_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, uphMapGrid(m), tp.as<double>(), n, tv.as<double>(), tg.as<double>());
     HIPCHK(hipGetLastError());

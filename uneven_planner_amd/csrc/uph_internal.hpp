@@ -10,6 +10,13 @@ void setError(const std::string& s);
 }
 
 int uphMapDevice(const uph_map* m);
+// grow-only device scratch owned by the map (slots 0..3), for the batched query entry points: no allocation per call once warm.
+// One query at a time per map.  nullptr (with uph_last_error set) when the allocation fails.
+void* uphMapScratch(uph_map* m, int slot, size_t bytes);
+struct UphPtr {                 // non-owning view of a scratch slot
+    void* p = nullptr;
+    template <class T> T* as() { return (T*)p; }
+};
 uph::GridDev uphMapGrid(const uph_map* m);
 
 // scope guards for the temporaries of the extern "C" entry points: every early return (HIPCHK) releases them
