@@ -227,7 +227,8 @@ int uph_ctx_set_lanes(uph_ctx* c, int32_t lanes);
 int uph_ctx_set_wps(uph_ctx* c, int32_t wps);
 /* BASELINE.json configs[4] "fp32": bits = 32 makes the sample phase of the objective (polynomial evaluation, terrain lookup, penalties and
  * their chain rule: alm_traj_opt.cpp:716-988) compute in fp32 -- MINCO, the gradient reduction, L-BFGS and ALM stay fp64.  The reference is
- * double-only: results are then NOT comparable at 1e-9, only through cost / feasibility statistics (tests/test_gpu_km2.py).  64 = default. */
+ * double-only: results are then NOT comparable at 1e-9, only through cost / feasibility statistics (tests/test_gpu_km2.py).  64 = default.
+ * Applies to the solve and evaluation kernels of 128 / 256 / 512 lanes (every automatic selection); a forced 64-lane context stays fp64. */
 int uph_ctx_set_sample_precision(uph_ctx* c, int32_t bits);
 int uph_ctx_set_rho(uph_ctx* c, double rho);
 int uph_ctx_get_rho(uph_ctx* c, double* rho);
