@@ -177,6 +177,19 @@ def main():
             torch.cuda.synchronize()
             extras["traj_opts_per_s_B%d" % Bx] = Bx * 3 / (time.perf_counter() - t1)
             del o2
+        # configs[4] "fp32" on the same scene: fp32 arithmetic in the sample phase (uph_ctx_set_sample_precision), B = 8192, three solves
+        if args.batch >= 8192 and not args.fp32:
+            o3 = U.ALMTrajOpt(m)
+            o3.set_sample_precision(32)
+            o3.upload(probs[:8192])
+            o3.set_rho(1.0); o3.solve()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                o3.set_rho(1.0); o3.solve()
+            torch.cuda.synchronize()
+            extras["traj_opts_per_s_B8192_fp32_samples"] = 8192 * 3 / (time.perf_counter() - t1)
+            del o3
     opt.upload(probs)
 
     kernel_ms, prepare_ms, evals, sample_evals, iters, hist_bytes = [], [], 0, 0, 0, 0

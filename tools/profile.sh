@@ -33,12 +33,12 @@ pmc() { name=$1; shift
   rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-extras > $OUT/$name.json 2> $OUT/$name.err
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   python - "$f" "$OUT/pmc_summary.txt" <<'PY'
-import sys, csv, collections
+import sys, csv, collections, re
 agg = collections.defaultdict(float); calls = collections.defaultdict(int)
 with open(sys.argv[1]) as fh:
     for row in csv.DictReader(fh):
         k = row['Kernel_Name'].replace(' ', '')
-        if 'uph_solver_kernel' in k and (k.endswith(',2>(uph::GridDev,uph::OptParams,uph::BatchDev,int)') or 'Li2EEv' in k):
+        if re.search(r'uph_solver_kernel<\d+,\d+,2(,(false|true))?>', k) or re.search(r'uph_solver_kernelILi\d+ELi\d+ELi2E', k):     # MODE 2 = the solve
             agg[row['Counter_Name']] += float(row['Counter_Value']); calls[row['Counter_Name']] += 1
 with open(sys.argv[2], 'a') as out:
     for k, v in sorted(agg.items()):
