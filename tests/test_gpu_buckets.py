@@ -2,7 +2,7 @@
 
 The reference's stop rules are loose and its L-BFGS amplifies rounding noise by ~1.25x per iteration, so the CPU oracle is not
 reproducible with ITSELF beyond a few hundred iterations: rebuilt with FMA contraction (nothing else changed) it agrees with its
-plain build to 1e-4 on every short solve and on almost no long one (profiles/r02_parity_buckets.json).  The
+plain build to 1e-4 on every short solve and on almost no long one (profiles/r02f_parity_buckets.json).  The
 enforceable statement is therefore per bucket of the oracle's total L-BFGS iterations:
   * wherever the oracle reproduces itself on 100 % of the problems, the device must reproduce the oracle on 100 % -- the 1e-4 bar, outright;
   * elsewhere the device's agreement rate must not fall behind the oracle's own by more than the sampling noise of the bucket.
