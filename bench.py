@@ -65,6 +65,8 @@ def main():
                                                          "start in its slab (owner routing, SURVEY.md 8e row 3) instead of replicating the grid")
     ap.add_argument("--fp32", action="store_true", help="fp32 arithmetic in the sample phase of the objective (uph_ctx_set_sample_precision(32); configs[4] \"fp32\"); "
                                                         "the line then says dtype \"f32 samples / f64 solver\"")
+    ap.add_argument("--pipelined", action="store_true", help="additionally measure two contexts driven alternately with uph_batch_solve_async / uph_batch_wait "
+                                                             "(the tail of one launch overlaps the head of the next); reported under \"pipelined\", the headline stays synchronous")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = automatic: 128 for large batches)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="also time the CPU oracle with this many threads (one trajectory per thread; context only)")
     args = ap.parse_args()
@@ -210,6 +212,29 @@ def main():
 
     out = opt.download()
     rets = np.array([o["ret"] for o in out])
+    pipelined = None
+    if args.pipelined:
+        # two contexts, each with its own stream and its own copy of the batch, launched alternately: K solves in total
+        ctxs = [opt, U.ALMTrajOpt(m)]
+        if args.lanes:
+            ctxs[1].set_lanes(args.lanes)
+        ctxs[1].upload(probs)
+        for c_ in ctxs:
+            c_.set_rho(1.0); c_.solve()
+        barrier()
+        t1 = time.perf_counter()
+        ctxs[0].set_rho(1.0); ctxs[0].solve_async()
+        for k_ in range(1, args.steps):
+            ctxs[k_ % 2].set_rho(1.0); ctxs[k_ % 2].solve_async()
+            ctxs[(k_ - 1) % 2].wait()
+        ctxs[(args.steps - 1) % 2].wait()
+        barrier()
+        pdt = time.perf_counter() - t1
+        if distributed:
+            tm2 = torch.tensor([pdt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+            pdt = float(tm2.item())
+        pipelined = {"value": args.batch * world * args.steps / pdt, "unit": "traj-opts/s", "contexts": 2, "ms_per_step": pdt / args.steps * 1e3}
 
     if rank == 0:
         K = args.steps
@@ -242,6 +267,8 @@ def main():
                          "sample_bytes_per_launch": sample_evals * bytes_per_sample / K, "history_bytes_per_launch": hist_bytes / K},
         }
         res.update(extras)
+        if pipelined:
+            res["pipelined"] = pipelined
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:
             from oracle import oracle_py as O
             nsamp = min(args.cpu_sample, len(probs))

@@ -245,6 +245,12 @@ int uph_optimize_batch(uph_ctx* c, int32_t B, const uph_problem* probs, uph_resu
 /* split form (inputs resident in HBM before the timed region): upload -> solve (kernel only, blocking) -> download */
 int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs);
 int uph_batch_solve(uph_ctx* c);
+/* the same solve split into enqueue and completion: uph_batch_solve_async returns after queuing the two kernels on the context's own HIP
+ * stream, uph_batch_wait blocks until they are done and collects the statistics (uph_batch_solve = the two back to back).  Contexts are
+ * independent, so two of them driven alternately keep the GPU full across batch boundaries (the tail of one launch overlaps the head of
+ * the next).  One asynchronous solve per context at a time; upload / download / hooks require a waited context. */
+int uph_batch_solve_async(uph_ctx* c);
+int uph_batch_wait(uph_ctx* c);
 int uph_batch_download(uph_ctx* c, uph_result* results);
 /* timing / work counters of the last uph_batch_solve: kernel ms (HIP events on the context's stream), total objective
  * evaluations, total constraint-sample evaluations, total L-BFGS iterations, bytes streamed from the L-BFGS history */

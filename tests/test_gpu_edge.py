@@ -148,3 +148,32 @@ def test_unsupported_problem_does_not_fail_its_neighbours(analytic_cells):
         opt.eval_batch(None)                                      # packed-array hooks need a clean batch
     with pytest.raises(U._lib.UnevenHipError):
         U.ALMTrajOpt(m).optimize_batch([short])                   # nothing solvable in the batch: an error, as before
+
+
+def test_async_solves_on_two_contexts_equal_the_blocking_ones(analytic_cells):
+    """uph_batch_solve_async / uph_batch_wait: two contexts in flight at once give exactly what each gives alone; misuse is refused"""
+    import uneven_planner_amd as U
+    from uneven_planner_amd import scenes
+    m = U.UnevenMap()
+    m.set_cells(analytic_cells)
+    pa = scenes.random_problems(300, seed0=8100, dmin=3.0, dmax=6.0)
+    pb = scenes.random_problems(300, seed0=8500, dmin=3.0, dmax=6.0)
+    ref = []
+    for pp in (pa, pb):
+        o = U.ALMTrajOpt(m)
+        o.set_rho(1.0)
+        ref.append(o.optimize_batch(pp))
+    a, b = U.ALMTrajOpt(m), U.ALMTrajOpt(m)
+    a.upload(pa); b.upload(pb)
+    a.set_rho(1.0); b.set_rho(1.0)
+    a.solve_async(); b.solve_async()
+    with pytest.raises(U._lib.UnevenHipError):
+        a.solve_async()                                   # one asynchronous solve per context
+    with pytest.raises(U._lib.UnevenHipError):
+        a.download()                                      # results only after the wait
+    b.wait(); a.wait()
+    with pytest.raises(U._lib.UnevenHipError):
+        a.wait()
+    for got, want in ((a.download(), ref[0]), (b.download(), ref[1])):
+        assert all(g["ret"] == w["ret"] and g["cost"] == w["cost"] and np.array_equal(g["x"], w["x"]) for g, w in zip(got, want))
+    assert a.stats()["evals"] == sum(o["evals"] for o in ref[0])

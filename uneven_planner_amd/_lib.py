@@ -97,6 +97,8 @@ SYMBOLS = {
     "uph_optimize_batch": (C.c_int, [_VP, _I32, C.POINTER(Problem), C.POINTER(Result)]),
     "uph_batch_upload": (C.c_int, [_VP, _I32, C.POINTER(Problem)]),
     "uph_batch_solve": (C.c_int, [_VP]),
+    "uph_batch_solve_async": (C.c_int, [_VP]),
+    "uph_batch_wait": (C.c_int, [_VP]),
     "uph_batch_download": (C.c_int, [_VP, C.POINTER(Result)]),
     "uph_batch_stats": (C.c_int, [_VP, DP, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
     "uph_batch_prepare_ms": (C.c_int, [_VP, DP]),

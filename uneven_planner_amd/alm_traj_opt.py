@@ -175,6 +175,13 @@ class ALMTrajOpt:
         """Kernel only (inputs already resident in HBM)."""
         _lib.check(self.L.uph_batch_solve(self.h), "uph_batch_solve")
 
+    def solve_async(self):
+        """enqueue the solve on this context's stream and return (uph_batch_solve_async); pair with wait()"""
+        _lib.check(self.L.uph_batch_solve_async(self.h), "uph_batch_solve_async")
+
+    def wait(self):
+        _lib.check(self.L.uph_batch_wait(self.h), "uph_batch_wait")
+
     def stats(self):
         ms = C.c_double(0)
         v = [C.c_int64(0) for _ in range(4)]

@@ -529,6 +529,8 @@ struct uph_ctx {
     int n_rejected = 0;
     bool sample_f32 = false;                // fp32 sample arithmetic (uph_ctx_set_sample_precision)
     hipStream_t stream2 = nullptr;
+    hipEvent_t evp0 = nullptr, evp1 = nullptr;      // prepare launch of an asynchronous solve
+    bool pending = false;                   // uph_batch_solve_async issued, uph_batch_wait not yet called
     hipEvent_t ev2 = nullptr;
     std::vector<size_t> fp_bytes;           // per-trajectory LDS footprint
     int lanes = 64;                         // lanes per trajectory of the current batch (64 or 256)
@@ -598,7 +600,10 @@ static int ensureOp(uph_ctx* c, int N) {
     return idx;
 }
 
-static int launchSolver(uph_ctx* c, int mode, int repeat) {
+// async: enqueue only (events evb / eve bracket the launch on the context's stream); the caller synchronises and reads the time later
+static int launchSolver(uph_ctx* c, int mode, int repeat, bool async = false, hipEvent_t evb = nullptr, hipEvent_t eve = nullptr) {
+    if (!async && c->pending) { setError("an asynchronous solve is in flight on this context: call uph_batch_wait first"); return UPH_ERR_INVALID; }
+    if (!evb) { evb = c->ev0; eve = c->ev1; }
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     GridDev grid = uphMapGrid(c->map);
     if (c->d_gridmem.ensure(sizeof(GridDev))) return UPH_ERR_HIP;
@@ -613,14 +618,14 @@ static int launchSolver(uph_ctx* c, int mode, int repeat) {
     do {                                                                                                                             \
         const size_t ldsmax = c->lds_big > c->lds_bytes ? c->lds_big : c->lds_bytes;                                                 \
         HIPCHK(hipFuncSetAttribute((const void*)uph_solver_kernel<NTL, WPS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax)); \
-        HIPCHK(hipEventRecord(c->ev0, c->stream));                                                                                   \
+        HIPCHK(hipEventRecord(evb, c->stream));                                                                                   \
         BatchDev bm = bd;                                                                                                            \
         bm.B = c->n_main;                                                                                                            \
         if (c->n_main < c->B) {           /* oversize class: same kernel, own LDS size, concurrent on the high-priority stream2 and */ \
             BatchDev bb = bd;             /* submitted first: these are the longest solves of the batch (longest-first scheduling)  */ \
             bb.B = c->B - c->n_main;                                                                                                 \
             bb.order = bd.order + c->n_main;                                                                                         \
-            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev0, 0));                                                                       \
+            HIPCHK(hipStreamWaitEvent(c->stream2, evb, 0));                                                                       \
             hipLaunchKernelGGL((uph_solver_kernel<NTL, WPS, MODE>), dim3(bb.B), dim3(NTL), c->lds_big, c->stream2, grid, c->P, bb, repeat); \
             HIPCHK(hipEventRecord(c->ev2, c->stream2));                                                                              \
         }                                                                                                                            \
@@ -640,14 +645,14 @@ static int launchSolver(uph_ctx* c, int mode, int repeat) {
     do {                                                                                                                             \
         const size_t ldsmax = c->lds_big > c->lds_bytes ? c->lds_big : c->lds_bytes;                                                 \
         HIPCHK(hipFuncSetAttribute((const void*)uph_solver_kernel<NTL, WPS, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax)); \
-        HIPCHK(hipEventRecord(c->ev0, c->stream));                                                                                   \
+        HIPCHK(hipEventRecord(evb, c->stream));                                                                                   \
         BatchDev bm = bd;                                                                                                            \
         bm.B = c->n_main;                                                                                                            \
         if (c->n_main < c->B) {                                                                                                      \
             BatchDev bb = bd;                                                                                                        \
             bb.B = c->B - c->n_main;                                                                                                 \
             bb.order = bd.order + c->n_main;                                                                                         \
-            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev0, 0));                                                                       \
+            HIPCHK(hipStreamWaitEvent(c->stream2, evb, 0));                                                                       \
             hipLaunchKernelGGL((uph_solver_kernel<NTL, WPS, MODE, true>), dim3(bb.B), dim3(NTL), c->lds_big, c->stream2, grid, c->P, bb, repeat); \
             HIPCHK(hipEventRecord(c->ev2, c->stream2));                                                                              \
         }                                                                                                                            \
@@ -679,10 +684,11 @@ static int launchSolver(uph_ctx* c, int mode, int repeat) {
 #undef UPH_LAUNCH32
 #undef UPH_LAUNCH
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventRecord(eve, c->stream));
+    if (async) return UPH_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    HIPCHK(hipEventElapsedTime(&ms, evb, eve));
     c->last_ms = ms;
     return UPH_OK;
 }
@@ -730,6 +736,7 @@ int uph_ctx_create(uph_map* m, const uph_opt_params* p, uph_ctx** out) {
         HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi));
     }
     HIPCHK(hipEventCreate(&c->ev2));
+    HIPCHK(hipEventCreate(&c->evp0)); HIPCHK(hipEventCreate(&c->evp1));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     *out = c;
@@ -748,6 +755,8 @@ void uph_ctx_destroy(uph_ctx* c) {
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->ev2) hipEventDestroy(c->ev2);
+    if (c->evp0) hipEventDestroy(c->evp0);
+    if (c->evp1) hipEventDestroy(c->evp1);
     delete c;
 }
 
@@ -777,6 +786,7 @@ int uph_ctx_get_trace(uph_ctx* c, double* out /* B x cap */) {
 
 int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     if (!c || B <= 0 || !probs) { setError("uph_batch_upload: bad arguments"); return UPH_ERR_INVALID; }
+    if (c->pending) { setError("uph_batch_upload: an asynchronous solve is in flight (uph_batch_wait first)"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     const int K1 = c->P.int_K + 1, mem = c->P.mem_size;
     c->B = 0;                       // the context holds no batch until this upload has succeeded as a whole
@@ -919,18 +929,34 @@ static int refreshStates(uph_ctx* c) {
     return UPH_OK;
 }
 
-int uph_batch_solve(uph_ctx* c) {
-    if (!c || c->B <= 0) { setError("uph_batch_solve: no batch uploaded"); return UPH_ERR_INVALID; }
+// enqueue one solve of the uploaded batch on the context's stream and return: reset + initScaling kernel, then the ALM kernel.  Two
+// contexts driven this way overlap on the GPU -- the second batch's workgroups fill the CUs the first one's tail leaves idle.
+int uph_batch_solve_async(uph_ctx* c) {
+    if (!c || c->B <= 0) { setError("uph_batch_solve_async: no batch uploaded"); return UPH_ERR_INVALID; }
+    if (c->pending) { setError("uph_batch_solve_async: the previous asynchronous solve has not been waited for"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     // every problem starts from the context's rho (Q7)
     for (int b = 0; b < c->B; b++) { std::memset(&c->state_host[b], 0, sizeof(TrajState)); c->state_host[b].rho = c->rho; c->state_host[b].scale_fx = 1.0; }
     HIPCHK(hipMemcpyAsync(c->d_state.p, c->state_host.data(), sizeof(TrajState) * c->B, hipMemcpyHostToDevice, c->stream));
-    int r = launchSolver(c, 1, 1);          // reset + initScaling (alm_traj_opt.cpp:193-203, 231-232)
+    int r = launchSolver(c, 1, 1, true, c->evp0, c->evp1);      // reset + initScaling (alm_traj_opt.cpp:193-203, 231-232)
     if (r != UPH_OK) return r;
-    c->last_prepare_ms = c->last_ms;
-    r = launchSolver(c, 2, 0);              // ALM loop (alm_traj_opt.cpp:234-271)
+    r = launchSolver(c, 2, 0, true, c->ev0, c->ev1);            // ALM loop (alm_traj_opt.cpp:234-271)
     if (r != UPH_OK) return r;
-    r = refreshStates(c);
+    c->pending = true;
+    return UPH_OK;
+}
+
+int uph_batch_wait(uph_ctx* c) {
+    if (!c || !c->pending) { setError("uph_batch_wait: no asynchronous solve in flight"); return UPH_ERR_INVALID; }
+    HIPCHK(hipSetDevice(uphMapDevice(c->map)));
+    c->pending = false;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->evp0, c->evp1));
+    c->last_prepare_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms = ms;
+    int r = refreshStates(c);
     if (r != UPH_OK) return r;
     c->last_evals = c->last_sample_evals = c->last_iters = c->last_hist_bytes = 0;
     for (int b = 0; b < c->B; b++) {
@@ -943,6 +969,11 @@ int uph_batch_solve(uph_ctx* c) {
     }
     if (c->B == 1 && !c->rejected[0]) c->rho = c->state_host[0].rho;      // one optimizeSE2Traj call: rho persists into the next (Q7).  A batch has no "next": unchanged
     return UPH_OK;
+}
+
+int uph_batch_solve(uph_ctx* c) {
+    const int r = uph_batch_solve_async(c);
+    return r != UPH_OK ? r : uph_batch_wait(c);
 }
 
 int uph_batch_stats(uph_ctx* c, double* kernel_ms, int64_t* evals, int64_t* sample_evals, int64_t* lbfgs_iters, int64_t* hist_bytes) {
@@ -967,6 +998,7 @@ int uph_batch_cycles(uph_ctx* c, long long* out) {
 
 int uph_batch_download(uph_ctx* c, uph_result* results) {
     if (!c || c->B <= 0 || !results) { setError("uph_batch_download: bad arguments"); return UPH_ERR_INVALID; }
+    if (c->pending) { setError("uph_batch_download: an asynchronous solve is in flight (uph_batch_wait first)"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     int r = refreshStates(c);
     if (r != UPH_OK) return r;
