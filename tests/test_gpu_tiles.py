@@ -30,6 +30,10 @@ def test_tiles_hold_the_whole_grids_cells_and_solve_identically():
         assert x0 <= a and b <= x1 and (x1 - x0) < nx
         t = U.UnevenMap(PARAMS, storage="f32", tile=(x0, x1)).fill_fbm()
         assert tuple(int(v) for v in t.voxel_num) == (nx, ny, nyaw) and t.occ_r2_buffer.shape == ((x1 - x0) * ny,)
+        import ctypes as C
+        a0, a1 = C.c_int32(-1), C.c_int32(-1)
+        assert t.L.uph_map_tile(t.h, C.byref(a0), C.byref(a1)) == 0 and (a0.value, a1.value) == (x0, x1)
+        assert full.L.uph_map_tile(full.h, C.byref(a0), C.byref(a1)) == 0 and (a0.value, a1.value) == (0, nx)
         # the tile's rows are the whole grid's rows, bit for bit (cells and occupancy)
         for xa in (x0, (x0 + x1) // 2, x1 - 3):
             assert np.array_equal(t.get_window(xa, xa + 3, 100, 140), full.get_window(xa, xa + 3, 100, 140))
