@@ -162,7 +162,7 @@ int uph_map_create(const uph_map_params* mp, int device, uph_map** out);
 /* the same grid with its cells stored as four floats (16 bytes) instead of four doubles: BASELINE.json configs[4]'s fp32 mode.  Lookups widen
  * to double on load and all arithmetic stays fp64; uph_map_build is refused, the cells come from uph_map_fill_fbm / uph_map_set_cells / import */
 int uph_map_create_f32(const uph_map_params* mp, int device, uph_map** out);
-int uph_map_storage_bytes(const uph_map* m);
+int uph_map_storage_bytes(const uph_map* m);                                                    /* 8 or 4: bytes per stored field */
 /* a TILE of the grid: only the x-rows [x0, x1) of the whole grid (uph_map_dims keeps reporting the whole grid) are held in memory -- for
  * grids that do not fit one GPU (1 km^2 at 0.05 m is 410 GB).  Index arithmetic is the whole grid's, so every lookup
  * inside the tile is bit-identical to the replicated grid; lookups outside are clamped to the tile.  Problems are routed on the host to the
@@ -170,7 +170,7 @@ int uph_map_storage_bytes(const uph_map* m);
  * uph_batch_download flags one that ended there (UPH_RET_LEFT_TILE).  Filled by uph_map_fill_fbm / uph_map_set_cells (held rows only);
  * uph_map_get_cells / get_window / occupancy cover the held rows. */
 int uph_map_create_tile(const uph_map_params* mp, int device, int32_t x0, int32_t x1, int32_t f32, uph_map** out);
-int uph_map_tile(const uph_map* m, int32_t* x0, int32_t* x1);                                  /* 8 or 4: bytes per stored field */
+int uph_map_tile(const uph_map* m, int32_t* x0, int32_t* x1);                                  /* the rows held: whole grid -> [0, nx) */
 /* fill the x-slab [x0, x1) (x1 <= 0: whole map) with the analytic fractal terrain: one constructMap-style plane fit per cell on a 5 x 3
  * body-frame lattice of surface samples; then commit.  uph_fbm_table returns the wave table a checker needs to restate the surface:
  * [UPH_FBM_MAX_WAVES][a, kx, ky, phase], ripples [4][kx, ky, phase], envelope [3][kx, ky, phase] */

@@ -270,19 +270,67 @@ public:
     }
 
     SE2Trajectory getTraj() const {                        // alm_traj_opt.h:165-168
-        SE2Trajectory t;
-        const int Nxy = (int)cxy_.size() / 12, Nyaw = (int)cyaw_.size() / 6;
-        for (int i = 0; i < Nxy; i++) {
-            Piece<2> p; p.duration = last_.piece_T_xy;
-            for (int d = 0; d < 2; d++) for (int k = 0; k < 6; k++) p.coeff[d][5 - k] = cxy_[(size_t)(6 * i + k) * 2 + d];
-            t.pos_traj.emplace_back(p);
+        return makeTraj(cxy_.data(), (int)cxy_.size() / 12, last_.piece_T_xy, cyaw_.data(), (int)cyaw_.size() / 6, last_.piece_T_yaw);
+    }
+
+    // ---- batch form (no counterpart in the reference: many candidate goals in one call).  paths[b] = the poses (x, y, yaw) the front-end
+    // returned for goal b (kino_astar->plan, plan_manager.cpp:56-60; any container of things indexable by [0..2], e.g.
+    // std::vector<Eigen::Vector3d>).  Runs the stage of plan_manager.cpp:62-132 for all of them (uph_resample_batch), one
+    // uph_optimize_batch, and returns one trajectory + return code per path.  ret[b] == UPH_RET_UNSUPPORTED marks a path outside the
+    // compiled limits (its trajectory is empty); rho is left as it was (a batch has no "next call").
+    struct BatchPlan {
+        std::vector<int> ret;
+        std::vector<SE2Trajectory> traj;
+        std::vector<double> jerk_cost, total_time;
+    };
+    template <class Path>
+    BatchPlan optimizeSE2TrajBatch(const std::vector<Path>& paths, const uph_manager_params& mgr) {
+        const int32_t B = (int32_t)paths.size(), cap_xy = 2 * UPH_MAX_PIECE_XY, cap_yaw = 2 * UPH_MAX_PIECE_YAW;
+        BatchPlan out;
+        if (B == 0) return out;
+        std::vector<int64_t> off((size_t)B + 1, 0);
+        for (int32_t b = 0; b < B; b++) off[b + 1] = off[b] + (int64_t)paths[b].size();
+        std::vector<double> flat((size_t)off[B] * 3);
+        for (int32_t b = 0; b < B; b++)
+            for (size_t i = 0; i < paths[b].size(); i++)
+                for (int k = 0; k < 3; k++) flat[((size_t)off[b] + i) * 3 + k] = paths[b][i][k];
+        std::vector<double> ixy((size_t)B * 6), exy((size_t)B * 6), iyw((size_t)B * 3), eyw((size_t)B * 3), oxy((size_t)B * 2 * cap_xy), oyw((size_t)B * cap_yaw), tt(B);
+        std::vector<int32_t> nxy(B), nyw(B);
+        if (uph_resample_batch(&mgr, B, flat.data(), off.data(), cap_xy, cap_yaw, ixy.data(), exy.data(), iyw.data(), eyw.data(), oxy.data(), oyw.data(),
+                               nxy.data(), nyw.data(), tt.data(), nullptr) != UPH_OK)
+            throw std::runtime_error(std::string("uph_resample_batch: ") + uph_last_error());
+        std::vector<uph_problem> pr(B);
+        std::vector<uph_result> rs(B);
+        std::vector<size_t> ox(B), oc(B), oy(B);
+        size_t sx = 0, sc = 0, sy = 0;
+        for (int32_t b = 0; b < B; b++) {
+            ox[b] = sx; oc[b] = sc; oy[b] = sy;
+            sx += (size_t)2 * nxy[b] + nyw[b] + 1; sc += (size_t)12 * (nxy[b] + 1); sy += (size_t)6 * (nyw[b] + 1);
         }
-        for (int i = 0; i < Nyaw; i++) {
-            Piece<1> p; p.duration = last_.piece_T_yaw;
-            for (int k = 0; k < 6; k++) p.coeff[0][5 - k] = cyaw_[(size_t)6 * i + k];
-            t.yaw_traj.emplace_back(p);
+        std::vector<double> xs(sx, 0.0), cx(sc, 0.0), cy(sy, 0.0);
+        for (int32_t b = 0; b < B; b++) {
+            uph_problem& p = pr[b];
+            p.n_inner_xy = nxy[b]; p.n_inner_yaw = nyw[b];
+            for (int k = 0; k < 6; k++) { p.init_xy[k] = ixy[(size_t)6 * b + k]; p.end_xy[k] = exy[(size_t)6 * b + k]; }
+            for (int k = 0; k < 3; k++) { p.init_yaw[k] = iyw[(size_t)3 * b + k]; p.end_yaw[k] = eyw[(size_t)3 * b + k]; }
+            p.inner_xy = oxy.data() + (size_t)2 * cap_xy * b;
+            p.inner_yaw = oyw.data() + (size_t)cap_yaw * b;
+            p.total_time = tt[b];
+            rs[b] = uph_result{};
+            rs[b].x_final = xs.data() + ox[b]; rs[b].c_xy = cx.data() + oc[b]; rs[b].c_yaw = cy.data() + oy[b];
         }
-        return t;
+        in_opt = true;
+        const int rc = uph_optimize_batch(ctx_, B, pr.data(), rs.data());
+        in_opt = false;
+        if (rc != UPH_OK) throw std::runtime_error(std::string("uph_optimize_batch: ") + uph_last_error());
+        for (int32_t b = 0; b < B; b++) {
+            out.ret.push_back(rs[b].ret_code);
+            out.jerk_cost.push_back(rs[b].jerk_cost);
+            out.total_time.push_back(tt[b]);
+            out.traj.push_back(rs[b].ret_code == UPH_RET_UNSUPPORTED ? SE2Trajectory()
+                                   : makeTraj(cx.data() + oc[b], nxy[b] + 1, rs[b].piece_T_xy, cy.data() + oy[b], nyw[b] + 1, rs[b].piece_T_yaw));
+        }
+        return out;
     }
     double getTrajJerkCost() const { return last_.jerk_cost; }   // minco_se2.getTrajJerkCost() (alm_traj_opt.cpp:273)
 
@@ -300,6 +348,22 @@ public:
     void visSE3Traj(const SE2Trajectory&) {}
 
 private:
+    // coefficient blocks of the C-ABI (lowest order first, xy interleaved per row) -> pieces with the highest order first (se2traj.hpp:682-695)
+    static SE2Trajectory makeTraj(const double* cxy, int Nxy, double Txy, const double* cyaw, int Nyaw, double Tyaw) {
+        SE2Trajectory t;
+        for (int i = 0; i < Nxy; i++) {
+            Piece<2> p; p.duration = Txy;
+            for (int d = 0; d < 2; d++) for (int k = 0; k < 6; k++) p.coeff[d][5 - k] = cxy[(size_t)(6 * i + k) * 2 + d];
+            t.pos_traj.emplace_back(p);
+        }
+        for (int i = 0; i < Nyaw; i++) {
+            Piece<1> p; p.duration = Tyaw;
+            for (int k = 0; k < 6; k++) p.coeff[0][5 - k] = cyaw[(size_t)6 * i + k];
+            t.yaw_traj.emplace_back(p);
+        }
+        return t;
+    }
+
     UnevenMapHandle* env_ = nullptr;
     uph_ctx* ctx_ = nullptr;
     uph_result last_{};

@@ -109,6 +109,14 @@ int plan_once(UnevenMapHandle& map, const Mat& init_xy, const Mat& end_xy, const
     if (m2.pos_pts.size() != traj_msg.pos_pts.size() || m2.angleT_pts.size() != traj_msg.angleT_pts.size()) return -100;
     return rc + (traj_opt.getTrajJerkCost() > 0 ? 0 : 10);
 }
+
+// many candidate goals at once: the front-end's pose lists go in, one trajectory and return code per goal comes out
+ALMTrajOpt::BatchPlan plan_many(UnevenMapHandle& map, const std::vector<std::vector<VecN<3>>>& paths) {
+    ALMTrajOpt traj_opt;
+    traj_opt.setEnvironment(&map);
+    const uph_manager_params mgr = {0.3, 0.5, 1.2, 2.0, 0.05};           // plan_manager/params/run_hill.yaml:57-62
+    return traj_opt.optimizeSE2TrajBatch(paths, mgr);
+}
 """
 
 

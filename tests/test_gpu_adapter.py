@@ -50,6 +50,105 @@ int main(int argc, char** argv) {
 """
 
 
+MAIN_BATCH = r"""
+#include <cstdio>
+#include <cstdlib>
+static std::vector<double> readv(FILE* f, size_t n) { std::vector<double> v(n); if (fread(v.data(), 8, n, f) != n) { std::fprintf(stderr, "short read\n"); std::exit(3); } return v; }
+int main(int argc, char** argv) {
+    // in: header {ncell, B}, cells[ncell*4], B x {M, poses[M*3]}
+    FILE* f = std::fopen(argv[1], "rb");
+    long long hdr[2];
+    if (!f || fread(hdr, 8, 2, f) != 2) return 2;
+    std::vector<double> cells = readv(f, (size_t)hdr[0] * 4);
+    std::vector<std::vector<VecN<3>>> paths((size_t)hdr[1]);
+    for (auto& p : paths) {
+        long long M;
+        if (fread(&M, 8, 1, f) != 1) return 2;
+        std::vector<double> v = readv(f, (size_t)M * 3);
+        p.resize((size_t)M);
+        for (long long i = 0; i < M; i++) for (int k = 0; k < 3; k++) p[i][k] = v[3 * i + k];
+    }
+    std::fclose(f);
+    uph_map_params mp = {2, 10.0, 10.0, 0.2, 0.1, 0.1, 0.05, 0.1, 0.8, 0.05, 9.81};
+    UnevenMapHandle map(mp, 0);
+    map.setCells(cells.data());
+    ALMTrajOpt::BatchPlan out = plan_many(map, paths);
+    // out: per path {ret, jerk_cost, total_time, npos, nang, pos_pts xy, posT, angle_pts, angleT}
+    FILE* o = std::fopen(argv[2], "wb");
+    for (size_t b = 0; b < paths.size(); b++) {
+        SE2TrajMsg msg;
+        if (out.traj[b].pos_traj.getPieceNum() > 0) fillSE2TrajMsg(out.traj[b], msg);
+        double head[5] = {(double)out.ret[b], out.jerk_cost[b], out.total_time[b], (double)msg.pos_pts.size(), (double)msg.angle_pts.size()};
+        fwrite(head, 8, 5, o);
+        for (const Point3& p : msg.pos_pts) { fwrite(&p.x, 8, 1, o); fwrite(&p.y, 8, 1, o); }
+        fwrite(msg.posT_pts.data(), 8, msg.posT_pts.size(), o);
+        for (const Point3& p : msg.angle_pts) fwrite(&p.x, 8, 1, o);
+        fwrite(msg.angleT_pts.data(), 8, msg.angleT_pts.size(), o);
+    }
+    std::fclose(o);
+    return 0;
+}
+"""
+
+
+def _build(tmp_path, name, text):
+    src = tmp_path / (name + ".cpp")
+    src.write_text(text)
+    exe = str(tmp_path / name)
+    libdir = os.path.join(ROOT, "uneven_planner_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe, "-L", libdir, "-lunevenhip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_batch_plan_matches_ctypes_bit_for_bit(tmp_path, analytic_cells):
+    """ALMTrajOpt::optimizeSE2TrajBatch (front-end paths -> uph_resample_batch -> uph_optimize_batch -> trajectories) from C++ against
+    resample_batch + optimize_batch through ctypes; one path is too short to optimise and must come back UNSUPPORTED without disturbing
+    the others"""
+    import uneven_planner_amd as U
+    from uneven_planner_amd import resample
+    rng = np.random.default_rng(21)
+    paths = []
+    for _ in range(6):
+        s = np.array([rng.uniform(-4, -1), rng.uniform(-4, 4), rng.uniform(-1, 1)])
+        g = np.array([rng.uniform(1, 4), rng.uniform(-4, 4), rng.uniform(-1, 1)])
+        paths.append(resample.hermite_path(s, g))
+    paths.insert(3, resample.hermite_path((0.0, 0.0, 0.0), (0.2, 0.0, 0.0)))          # shorter than one piece: no inner way-point
+    exe = _build(tmp_path, "batch_consumer", CONSUMER + MAIN_BATCH)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    cells = np.ascontiguousarray(analytic_cells, dtype=np.float64)
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<2q", cells.shape[0], len(paths)))
+        f.write(cells.tobytes())
+        for p in paths:
+            f.write(struct.pack("<q", p.shape[0]))
+            f.write(np.ascontiguousarray(p, dtype=np.float64).tobytes())
+    subprocess.check_call([exe, fin, fout])
+    raw = np.fromfile(fout, dtype=np.float64)
+    m = U.UnevenMap()
+    m.set_cells(analytic_cells)
+    opt = U.ALMTrajOpt(m)
+    probs = resample.resample_batch(paths, cap_xy=128, cap_yaw=256)
+    out = opt.optimize_batch(probs)
+    o = 0
+    for b, pr in enumerate(probs):
+        ret, jc, tt, npos, nang = raw[o:o + 5]; o += 5
+        npos, nang = int(npos), int(nang)
+        assert int(ret) == out[b]["ret"] and tt == pr["total_time"]
+        if b == 3:
+            assert int(ret) == 4 and npos == 0 and nang == 0                     # UPH_RET_UNSUPPORTED
+            continue
+        msg = opt.getTraj(b).to_msg()
+        pos = raw[o:o + 2 * npos].reshape(npos, 2); o += 2 * npos
+        posT = raw[o:o + npos - 1]; o += npos - 1
+        ang = raw[o:o + nang]; o += nang
+        angT = raw[o:o + nang - 1]; o += nang - 1
+        assert jc == out[b]["jerk_cost"]
+        assert np.array_equal(pos, msg["pos_pts"][:, :2]) and np.array_equal(ang, msg["angle_pts"][:, 0])
+        assert np.array_equal(posT, msg["posT_pts"]) and np.array_equal(angT, msg["angleT_pts"])
+    assert o == raw.size
+
+
 def _locate(durs, t):                      # PolyTrajectory::locatePieceIdx (se2traj.hpp:343-361)
     idx = 0
     while idx < len(durs) and t > durs[idx]:
