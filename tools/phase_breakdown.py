@@ -32,3 +32,8 @@ if ok.any():
     busy = (res[:-1] * dt).sum() / full
     print('launch span %.1f ms, peak residency %d workgroups, residency-weighted time %.1f ms (= %.1f %% of the span), time below 90 %% residency %.1f ms'
           % (span * 1e3, full, busy * 1e3, 100 * busy / span, dt[res[:-1] < 0.9 * full].sum() * 1e3))
+# two-loop profile (library built with -DUPH_TL_PROF): per call, cycles of loop 1 / loop 2 / tail, first-row latency, mean bound
+if cy[:, 12].sum() > 0:
+    calls = cy[:, 12].sum()
+    print('two-loop per call: loop1 %.0f loop2 %.0f tail %.0f  first-row wait %.0f  mean bound %.1f  calls/traj %.0f'
+          % (cy[:, 8].sum() / calls, cy[:, 9].sum() / calls, cy[:, 10].sum() / calls, cy[:, 13].sum() / calls, cy[:, 11].sum() / calls, calls / len(cy)))

@@ -1173,6 +1173,9 @@ struct Solver {
         wg.pfor(1, [&](int) {
             st.T_xy = Txy; st.T_yaw = Tyaw; st.jerk_cost = last_jerk; st.scale_fx = scale_fx; st.rho = rho;
             st.evals = evals; st.hist_reads = hist_reads;
+#ifdef UPH_TL_PROF
+            for (int q = 0; q < 6; q++) cyc[8 + q] = wg.tl[q];                  // two-loop profile of the device workgroup object
+#endif
             for (int q = 0; q < 16; q++) st.cyc[q] = cyc[q];
         });
     }

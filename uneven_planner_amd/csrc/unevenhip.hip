@@ -92,6 +92,9 @@ struct DevWG {
     static constexpr int SCRATCH = 2 * NW * MAXM;   // doubles of LDS
     double* red;
     int tid, lane, wave, par;
+#ifdef UPH_TL_PROF
+    long long tl[6] = {0, 0, 0, 0, 0, 0};   // two-loop profile (tools/phase_breakdown.py): loop 1, loop 2, tail, steps, calls, first-row wait
+#endif
     __device__ DevWG(double* scratch) : red(scratch), tid(threadIdx.x), lane(threadIdx.x & 63), wave(uni((int)(threadIdx.x >> 6))), par(0) {}
     // The lane index, re-read through an opaque barrier at the start of every parallel region: everything derived from it (LDS
     // addresses, task decompositions) is invariant across the solver's outer loops, so the compiler would otherwise hoist those
@@ -251,9 +254,15 @@ struct DevWG {
             for (int q = 0; q < NQ; q++) asm volatile("" : "+v"(dr[q]) : : "memory");
         };
         // ---- first loop: newest -> oldest
+#ifdef UPH_TL_PROF
+        const long long tp0 = __builtin_readcyclecounter();
+#endif
         int jf = end;                                            // row being fetched
 #pragma unroll
         for (int u = 0; u < PF; u++) { jf = jf == 0 ? m - 1 : jf - 1; fetch(u, jf); }
+#ifdef UPH_TL_PROF
+        { double probe = sr[0][0]; asm volatile("s_waitcnt vmcnt(0)" : "+v"(probe) : : "memory"); tl[5] += __builtin_readcyclecounter() - tp0; }
+#endif
         int i = 0;
         for (; i + PF <= bound; i += PF) {
 #pragma unroll
@@ -271,6 +280,11 @@ struct DevWG {
         }
 #pragma unroll
         for (int q = 0; q < NQ; q++) dr[q] *= scale;
+#ifdef UPH_TL_PROF
+        pin();
+        const long long tp1 = __builtin_readcyclecounter();
+        tl[0] += tp1 - tp0; tl[3] += bound; tl[4] += 1;
+#endif
         // ---- second loop: oldest -> newest, starting at the row the first loop ended on; step i2 pairs with first-loop step bound-1-i2
         jf = end - bound; jf = jf < 0 ? jf + m : jf;             // oldest stored pair
 #pragma unroll
@@ -289,12 +303,20 @@ struct DevWG {
 #pragma unroll
             for (int u = 0; u < PF - 1; u++) if (u < rem) step2(u, i + u);
         }
+#ifdef UPH_TL_PROF
+        pin();
+        const long long tp2 = __builtin_readcyclecounter();
+        tl[1] += tp2 - tp1;
+#endif
         // g . d for the next line search, while d is still in registers
         double gd = 0.0;
 #pragma unroll
         for (int q = 0; q < NQ; q++) { const int e = eidx(q); if (e < n) { d[e] = dr[q]; gd = fma(g[e], dr[q], gd); } }
         gd = waveSum(gd);
         if (lane == 0) *dg_out = gd;
+#ifdef UPH_TL_PROF
+        tl[2] += __builtin_readcyclecounter() - tp2;
+#endif
     }
     // ---------------------------------------------------------------------------------------------------------------------------
     // MINCO knot solve: block-tridiagonal sweeps with the precomputed 2x2 block-LU factors (minco_op_host.hpp; table in LDS).
