@@ -25,6 +25,9 @@ using namespace uph;
 #ifndef UPH_THOMAS_KPL
 #define UPH_THOMAS_KPL 4        // knots per lane of the knot solve: 64 lanes x 4 cover UPH_MAX_PIECE_YAW - 1 = 127 knots, 32 x 4 the 63 of an xy chain
 #endif
+#ifndef UPH_WPS128
+#define UPH_WPS128 2
+#endif
 #ifndef UPH_TWOLOOP_PF
 #define UPH_TWOLOOP_PF 5
 #endif
@@ -697,7 +700,7 @@ static int launchSolver(uph_ctx* c, int mode, int repeat, bool async = false, hi
     else if (c->lanes == 64 && c->wps_forced == 2) UPH_LAUNCH_MODE(64, 2);
     else if (c->lanes == 64) UPH_LAUNCH_MODE(64, 1);
     else if (c->lanes == 128 && mode == 1) UPH_LAUNCH(128, 1, 1);      // initScaling without the register cap: 410 VGPRs and no spills instead of 162 spilled at 256 (6.05 -> 5.39 ms at B = 8192)
-    else if (c->lanes == 128) UPH_LAUNCH_MODE(128, 2);
+    else if (c->lanes == 128) UPH_LAUNCH_MODE(128, UPH_WPS128);
     else if (c->lanes == 512) UPH_LAUNCH_MODE(512, 1);
     else if (c->wps == 2 && mode == 2 && c->lds_bytes <= 80 * 1024) UPH_LAUNCH(256, 2, 2);
     else if (c->wps == 2 && mode == 5 && c->lds_bytes <= 80 * 1024) UPH_LAUNCH(256, 2, 5);
