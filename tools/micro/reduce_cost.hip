@@ -80,6 +80,33 @@ template <> __device__ __forceinline__ double red<7>(double v) {
     }
     return v;
 }
+// 8: TWO different sums in one pass: permlane32_swap hands the upper half its partner's copy of the second value (the lower half keeps
+//    the first), four row_ror stages and one row_bcast:15 finish both; sum 1 ends in lane 31, sum 2 in lane 63
+__device__ __forceinline__ void red2(double& u, double& v) {
+    const bool up = (threadIdx.x & 32) != 0;
+    const double keep = up ? v : u, send = up ? u : v;
+    const unsigned lo = __double2loint(send), hi = __double2hiint(send);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    // a[0] = [lower half of send, lower half of send], a[1] = [upper, upper]: the partner's value is a[1] for the lower lanes, a[0] for the upper ones
+    const double got = __hiloint2double((int)(up ? b[0] : b[1]), (int)(up ? a[0] : a[1]));
+    double w = keep + got;
+    w += dppMov<0x128>(w); w += dppMov<0x124>(w); w += dppMov<0x122>(w); w += dppMov<0x121>(w);
+    w += dppMov<0x142, true>(w);
+    u = readLane(w, 31); v = readLane(w, 63);
+}
+__global__ void k2(double* out, long long* cyc, int iters) {
+    double u = 1.0 + threadIdx.x * 1e-3, v = 2.0 - threadIdx.x * 1e-3;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; i++) {
+        red2(u, v);
+        const double nu = u * 1e-2 + threadIdx.x * 1e-3, nv = v * 1e-2 - threadIdx.x * 1e-3;
+        u = nu; v = nv;
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    out[threadIdx.x] = u + 3.0 * v;
+    if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
 template <int V>
 __global__ void k(double* out, long long* cyc, int iters) {
     double v = 1.0 + threadIdx.x * 1e-3;
@@ -111,5 +138,15 @@ int main() {
     run<2>("quad_perm x2 + row_half_mirror + row_mirror + 8 readlanes + 3 adds", dout, dcyc);
     run<6>("ds_bpermute butterfly x6", dout, dcyc);
     run<7>("row_ror x4 + permlane16_swap + permlane32_swap", dout, dcyc);
+    {
+        const int iters = 20000;
+        k2<<<1, 64>>>(dout, dcyc, iters);
+        k2<<<1, 64>>>(dout, dcyc, iters);
+        long long c = 0; double o[64];
+        (void)hipMemcpy(&c, dcyc, 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(o, dout, 512, hipMemcpyDeviceToHost);
+        // reference for the first iteration is checked by value: u -> sum(1 + l/1000) = 66.016, v -> sum(2 - l/1000) = 125.984
+        printf("%-70s %7.1f cycles per iteration   (out = %.6g)\n", "TWO sums: permlane32_swap split + row_ror x4 + row_bcast15", (double)c / iters, o[0]);
+    }
     return 0;
 }
