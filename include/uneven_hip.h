@@ -46,9 +46,10 @@ typedef struct uph_ctx uph_ctx;   /* optimiser context bound to one map, one dev
 
 /* uph_result.ret_code beyond the reference's 0 / 1 / 2: */
 #define UPH_RET_STOPPED 3      /* test hook only: the ALM loop was stopped by uph_batch_alm_passes' pass cap                          */
-#define UPH_RET_UNSUPPORTED 4  /* the problem lies outside the compiled limits (no inner way-point in a block, i.e. a goal closer than
-                                  one piece length; more than UPH_MAX_PIECE_* pieces; piece_yaw < piece_xy): not solved, outputs untouched,
-                                  last_lbfgs_ret = the UPH_ERR_* reason.  The other problems of the batch are solved normally.            */
+#define UPH_RET_UNSUPPORTED 4  /* the problem lies outside the compiled limits (more than UPH_MAX_PIECE_* pieces; piece_yaw < piece_xy):
+                                  not solved, outputs untouched, last_lbfgs_ret = the UPH_ERR_* reason.  The other problems of the
+                                  batch are solved normally.  (A goal closer than one piece length -- n_inner_* = 0, a single quintic
+                                  piece per block -- IS solved, as the reference does.)                                               */
 
 #define UPH_RET_LEFT_TILE 5    /* tile maps only: the solved path reached the border of the rows the tile holds (lookups were clamped there) */
 #define UPH_TILE_MARGIN 2.0    /* [m] a problem is accepted by a tile map when its initial path keeps this distance from the tile's border */

@@ -143,3 +143,25 @@ def test_knot_minco_operator_reproduces_banded_solve(oracle):
         k = np.tile(np.arange(6), N)
         c = ct / (T ** k)[:, None]
         assert rel(c_ref, c) < 1e-11
+
+
+def test_single_piece_problems(emu, oracle, oracle_grid):
+    """piece_xy = 1 (goal closer than one piece length) and piece_yaw = 1: no knot system at all; evaluation, initScaling and the full solve
+    of the workgroup program against the oracle (the GPU tier repeats this through the C-ABI: test_gpu_edge.py)"""
+    from uneven_planner_amd import resample
+    E.lib().emu_set_lanes(128)
+    for dx, dy, dyaw in [(0.25, 0.02, 0.1), (0.12, 0.0, 0.0)]:
+        p = resample.make_problem((0.3, -0.2, 0.2), (0.3 + dx, -0.2 + dy, 0.2 + dyaw))
+        assert p["inner_xy"].shape[1] == 0
+        a = oracle.OracleALM(oracle_grid)
+        x0 = a.setup(p)
+        fo, go, _ = a.eval(x0)
+        r0 = emu.run(0, p, x0)
+        assert abs(r0["f"] - fo) / abs(fo) < 1e-11 and rel(go, r0["g"]) < 1e-10
+        a.init_scaling(x0)
+        st = a.get_state()
+        r1 = emu.run(1, p, x0)
+        assert abs(st["scale_fx"] - r1["scale_fx"]) / st["scale_fx"] < 1e-10 and rel(st["scale_cx"], r1["scale_cx"]) < 1e-10
+        ro = oracle.OracleALM(oracle_grid).optimize(p)
+        r2 = emu.run(2, p, x0)
+        assert r2["ret"] == ro["ret"] and r2["alm_iters"] == ro["alm_iters"] and np.abs(np.asarray(ro["x"]) - r2["x"]).max() < 1e-9

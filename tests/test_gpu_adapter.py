@@ -103,8 +103,8 @@ def _build(tmp_path, name, text):
 
 def test_cpp_batch_plan_matches_ctypes_bit_for_bit(tmp_path, analytic_cells):
     """ALMTrajOpt::optimizeSE2TrajBatch (front-end paths -> uph_resample_batch -> uph_optimize_batch -> trajectories) from C++ against
-    resample_batch + optimize_batch through ctypes; one path is too short to optimise and must come back UNSUPPORTED without disturbing
-    the others"""
+    resample_batch + optimize_batch through ctypes; one path is a single piece (goal closer than a piece length), one has more pieces than the
+    compiled limit and must come back UNSUPPORTED without disturbing the others"""
     import uneven_planner_amd as U
     from uneven_planner_amd import resample
     rng = np.random.default_rng(21)
@@ -113,7 +113,9 @@ def test_cpp_batch_plan_matches_ctypes_bit_for_bit(tmp_path, analytic_cells):
         s = np.array([rng.uniform(-4, -1), rng.uniform(-4, 4), rng.uniform(-1, 1)])
         g = np.array([rng.uniform(1, 4), rng.uniform(-4, 4), rng.uniform(-1, 1)])
         paths.append(resample.hermite_path(s, g))
-    paths.insert(3, resample.hermite_path((0.0, 0.0, 0.0), (0.2, 0.0, 0.0)))          # shorter than one piece: no inner way-point
+    paths.insert(2, resample.hermite_path((0.0, 0.0, 0.0), (0.2, 0.0, 0.0)))          # shorter than one piece: a single quintic, solved like the others
+    tl = np.linspace(-4.5, 4.5, 1200)
+    paths.insert(3, np.column_stack([tl, 4.0 * np.sin(1.5 * tl), np.arctan(6.0 * np.cos(1.5 * tl))]))      # > UPH_MAX_PIECE_XY pieces
     exe = _build(tmp_path, "batch_consumer", CONSUMER + MAIN_BATCH)
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     cells = np.ascontiguousarray(analytic_cells, dtype=np.float64)

@@ -121,21 +121,61 @@ def test_trajectory_leaving_the_map(devmap, oracle, oracle_grid):
     assert abs(f[0] - fo) / abs(fo) < 1e-9 and rel(go, g[0]) < 1e-9
 
 
+def test_single_piece_problems_match_oracle(analytic_cells, oracle, oracle_grid):
+    """a goal closer than one piece length has no inner position way-point (piece_xy = 1) and, below half a piece length, no inner yaw
+    way-point either (piece_yaw = 1): the reference solves the single quintic piece (no knot system), and so must the device --
+    evaluation, initScaling and the full solve against the oracle, alone and inside a batch of ordinary problems"""
+    import uneven_planner_amd as U
+    from uneven_planner_amd import resample, scenes
+    m = U.UnevenMap()
+    m.set_cells(analytic_cells)
+    shorts = [resample.make_problem((0.3, -0.2, 0.2), (0.3 + dx, -0.2 + dy, 0.2 + dyaw)) for dx, dy, dyaw in
+              [(0.25, 0.02, 0.1), (0.12, 0.0, 0.0), (0.2, -0.1, -0.3), (0.29, 0.0, 0.0)]]
+    assert [(p["inner_xy"].shape[1], p["inner_yaw"].shape[0]) for p in shorts] == [(0, 1), (0, 0), (0, 1), (0, 1)]
+    good = scenes.random_problems(2, seed0=2100, dmin=3.0, dmax=5.0)
+    for lanes in (128, 256, 512):
+        opt = U.ALMTrajOpt(m)
+        opt.set_lanes(lanes)
+        opt.upload(shorts)
+        f, gs = opt.eval_batch(opt.x0_packed(shorts))
+        opt.init_scaling_batch()
+        sc = opt.download()
+        opt.set_rho(1.0)
+        mixed = opt.optimize_batch([good[0]] + shorts + [good[1]])
+        for i, p in enumerate(shorts):
+            a = oracle.OracleALM(oracle_grid)
+            x0 = a.setup(p)
+            fo, go, _ = a.eval(x0)
+            assert abs(f[i] - fo) / abs(fo) < 1e-9 and rel(go, gs[i]) < 1e-9
+            a.init_scaling(x0)
+            st = a.get_state()
+            assert abs(sc[i]["scale_fx"] - st["scale_fx"]) / st["scale_fx"] < 1e-9 and rel(st["scale_cx"], sc[i]["scale_cx"]) < 1e-9
+            ro = oracle.OracleALM(oracle_grid).optimize(p)
+            o = mixed[1 + i]
+            # one or two variables and at most a dozen iterations per pass: no room for chaotic drift, the solves agree tightly
+            assert o["ret"] == ro["ret"] and o["alm_iters"] == ro["alm_iters"]
+            assert abs(o["cost"] - ro["cost"]) / abs(ro["cost"]) < 1e-8 and np.abs(o["x"] - np.asarray(ro["x"])).max() < 1e-8
+    alone = U.ALMTrajOpt(m)
+    alone.set_rho(1.0)
+    ref = alone.optimize_batch(good)
+    assert np.array_equal(ref[0]["x"], mixed[0]["x"]) and np.array_equal(ref[1]["x"], mixed[-1]["x"])
+
+
 def test_unsupported_problem_does_not_fail_its_neighbours(analytic_cells):
-    """a goal closer than one piece length (no inner position way-point; the reference would solve a single piece) or a path beyond
-    UPH_MAX_PIECE_XY gets ret_code UPH_RET_UNSUPPORTED; the other problems of the batch are solved exactly as they are alone"""
+    """a path beyond UPH_MAX_PIECE_XY (or with fewer yaw than position pieces) gets ret_code UPH_RET_UNSUPPORTED; the other problems of
+    the batch are solved exactly as they are alone"""
     import uneven_planner_amd as U
     from uneven_planner_amd import resample, scenes
     m = U.UnevenMap()
     m.set_cells(analytic_cells)
     good = scenes.random_problems(3, seed0=2100, dmin=3.0, dmax=5.0)
-    short = resample.make_problem((0.0, 0.0, 0.3), (0.2, 0.1, 0.5))
-    assert short["inner_xy"].shape[1] == 0
+    fewer_yaw = dict(good[0])
+    fewer_yaw["inner_yaw"] = good[0]["inner_yaw"][:good[0]["inner_xy"].shape[1] - 2]
     long_ = resample.resample_path(np.column_stack([np.linspace(-4.5, 4.5, 400), np.linspace(-4.4, 4.4, 400) ** 3 / 20.0, np.zeros(400)]), piece_len=0.12)
     assert long_["inner_xy"].shape[1] + 1 > 64
     opt = U.ALMTrajOpt(m)
     opt.set_rho(1.0)
-    out = opt.optimize_batch([good[0], short, good[1], long_, good[2]])
+    out = opt.optimize_batch([good[0], fewer_yaw, good[1], long_, good[2]])
     assert [o["ret"] for o in out][1::2] == [4, 4] and out[1]["last_lbfgs_ret"] == -1 and out[3]["last_lbfgs_ret"] == -4
     alone = U.ALMTrajOpt(m)
     alone.set_rho(1.0)
@@ -147,7 +187,7 @@ def test_unsupported_problem_does_not_fail_its_neighbours(analytic_cells):
     with pytest.raises(U._lib.UnevenHipError):
         opt.eval_batch(None)                                      # packed-array hooks need a clean batch
     with pytest.raises(U._lib.UnevenHipError):
-        U.ALMTrajOpt(m).optimize_batch([short])                   # nothing solvable in the batch: an error, as before
+        U.ALMTrajOpt(m).optimize_batch([long_])                   # nothing solvable in the batch: an error, as before
 
 
 def test_async_solves_on_two_contexts_equal_the_blocking_ones(analytic_cells):

@@ -70,9 +70,11 @@ inline void buildMincoOp(int N, std::vector<double>& Wt /* [col][row] */, std::v
         }
     }
     // knot rows: r = 2(j-1) -> v_j = c1 of piece j,  r = 2(j-1)+1 -> a_j = 2 c2 of piece j   (j = 1..N-1)
+    // (a single piece has no interior knot: two all-zero rows are kept so that readers with unconditional row loads and zero weights
+    // -- initScaling's per-sample gathers -- stay in bounds)
     const int nr = 2 * (N - 1);
-    Wt.assign((size_t)nr * nc, 0.0);
-    Wr.assign((size_t)nr * nc, 0.0);
+    Wt.assign((size_t)(nr > 2 ? nr : 2) * nc, 0.0);
+    Wr.assign((size_t)(nr > 2 ? nr : 2) * nc, 0.0);
     for (int j = 1; j < N; j++)
         for (int w = 0; w < 2; w++) {
             const int r = 2 * (j - 1) + w;

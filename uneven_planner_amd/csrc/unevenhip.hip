@@ -843,7 +843,8 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         const uph_problem& q = probs[b];
         int rj = 0;
         const char* msg = nullptr;
-        if (q.n_inner_xy < 1 || q.n_inner_yaw < 1 || !q.inner_xy || !q.inner_yaw) { rj = UPH_ERR_INVALID; msg = "uph_batch_upload: a problem needs at least one inner way-point per block"; }
+        // (a block without inner way-points is a single quintic piece -- a goal closer than one piece length; the reference solves it, and so does this)
+        if (q.n_inner_xy < 0 || q.n_inner_yaw < 0 || (q.n_inner_xy > 0 && !q.inner_xy) || (q.n_inner_yaw > 0 && !q.inner_yaw)) { rj = UPH_ERR_INVALID; msg = "uph_batch_upload: negative way-point count or missing way-point array"; }
         else if (q.n_inner_xy + 1 > UPH_MAX_PIECE_XY || q.n_inner_yaw + 1 > UPH_MAX_PIECE_YAW) { rj = UPH_ERR_LIMIT; msg = "uph_batch_upload: piece count exceeds UPH_MAX_PIECE_*"; }
         else if (q.n_inner_yaw < q.n_inner_xy) { rj = UPH_ERR_INVALID; msg = "uph_batch_upload: piece_yaw < piece_xy (the reference indexes yaw_minco.T1 with the xy piece index, alm_traj_opt.cpp:749)"; }
         else if (tiled) {                // a tile map serves the problems routed to it: the initial path must lie well inside the held rows (the grid's own border is no tile border)
