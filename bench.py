@@ -43,9 +43,103 @@ def pmc_traffic(batch, stream_bytes):
             return None
         fetch = t["fetch_kib"] * 1024.0 / max(1, t["launches"])
         write = t["write_kib"] * 1024.0 / max(1, t["launches"])
-        return fetch + min(fetch, 0.5 * stream_bytes) + write
+        return fetch + min(fetch, 0.5 * stream_bytes) + write, t.get("tag", "profiles/pmc_traffic.json")
     except Exception:
         return None
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, the same contract torch.distributed.run provides), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), UPH_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0]
+    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if any(codes) or not line:
+        sys.stderr.write("bench.py: ranks exited with %s\n%s\n" % (codes, out0 or ""))
+        raise SystemExit(1)
+    print(line[-1], flush=True)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def single_process(args):
+    """--single-process: what a one-process host (the reference's ROS node) gets from N GPUs through the C-ABI alone.  Map: uph_map_build_multi
+    (x-slab fits on N host threads + one in-library ncclAllGather).  Batch: one context per device, every device its own B problems
+    (weak scaling, seeds 1000 + g B + i as in the multi-process form), uph_batch_solve_async on all, then uph_batch_wait on all."""
+    import torch
+    import uneven_planner_amd as U
+    from uneven_planner_amd import scenes
+    N = args.gpus
+    if torch.cuda.device_count() < N:
+        raise SystemExit("bench.py --single-process: --gpus %d but only %d GPU(s) visible" % (N, torch.cuda.device_count()))
+    B = args.batch or 16384
+    xyz = scenes.make_hill_cloud()
+    maps = [U.UnevenMap(device=g) for g in range(N)]
+    t0 = time.time()
+    stages = U.UnevenMap.build_multi(maps, xyz)
+    map_build_s = time.time() - t0
+    t0 = time.time()
+    stages2 = U.UnevenMap.build_multi(maps, xyz, download=False)      # second call: the RCCL clique is cached
+    map_build_warm_s = time.time() - t0
+    m0 = maps[0]
+    nx, ny = int(m0.voxel_num[0]), int(m0.voxel_num[1])
+    gridinfo = (nx, ny, m0.xy_resolution, m0.map_origin[0], m0.map_origin[1])
+    opts, sizes = [], []
+    for g in range(N):
+        pr = scenes.random_problems(B, seed0=1000 + g * B, occ_r2=m0.occ_r2_buffer, grid=gridinfo)
+        o = U.ALMTrajOpt(maps[g])
+        if args.lanes:
+            o.set_lanes(args.lanes)
+        o.upload(pr)
+        opts.append(o)
+
+    def sync():
+        for g in range(N):
+            torch.cuda.synchronize(g)
+
+    def step():
+        for o in opts:
+            o.set_rho(1.0); o.solve_async()
+        for o in opts:
+            o.wait()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(args.steps):
+        step()
+        kms.append([o.stats()["kernel_ms"] for o in opts])
+    sync()
+    dt = time.perf_counter() - t0
+    rets = np.array([r["ret"] for r in opts[0].download(full=False)])
+    res = {"metric": "MINCO traj-opts/sec (batch)", "value": B * N * args.steps / dt, "unit": "traj-opts/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "hill scene (synthetic hill cloud, map built on the devices by uph_map_build_multi), batch of %d random start/goal full ALM solves per GPU, run_hill.yaml params" % B,
+                      "batch_per_gpu": B, "grid": [nx, ny, int(m0.voxel_num[2])], "launcher": "single process, C-ABI multi-GPU entries (no torch.distributed)", "parallelism": "dp%d" % N},
+           "per_gpu_kernel_ms": [float(v) for v in np.mean(np.array(kms), axis=0)], "converged_frac": float((rets == 0).mean()),
+           "map_build_multi": dict(first_call_s=map_build_s, warm_call_s=map_build_warm_s, first=stages, warm=stages2)}
+    print(json.dumps(res), flush=True)
 
 
 def main():
@@ -69,7 +163,18 @@ def main():
                                                              "(the tail of one launch overlaps the head of the next); reported under \"pipelined\", the headline stays synchronous")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per trajectory (0 = automatic: 128 for large batches)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="also time the CPU oracle with this many threads (one trajectory per thread; context only)")
+    ap.add_argument("--single-process", action="store_true", help="N > 1 without a launcher and without torch.distributed: ONE process drives all --gpus devices through "
+                                                                  "the C-ABI's own multi-GPU entries (uph_map_build_multi: host threads + in-library RCCL all-gather; one context per device "
+                                                                  "with uph_batch_solve_async) -- what a single-process host such as the reference's ROS node would do")
     args = ap.parse_args()
+    if os.environ.get("UPH_BENCH_SPAWN_ECHO") == "1" and "WORLD_SIZE" in os.environ:      # CPU-tier test of spawn_ranks (tests/test_dist_cpu.py): report the rank environment and leave
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")} | {"gpus": args.gpus}), flush=True)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
+        spawn_ranks(args.gpus, sys.argv[1:])
+        return
+    if args.single_process:
+        return single_process(args)
     km2 = args.workload == "km2"
     if not args.batch:
         args.batch = 4096 if km2 else 16384
@@ -77,8 +182,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d -- the launcher's world size is what runs and what n_gpus reports\n" % (args.gpus, world))
     import torch
     import torch.distributed as dist
+    if torch.cuda.device_count() < max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        raise SystemExit("bench.py: %d ranks on this node but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     distributed = world > 1 or os.environ.get("UPH_FORCE_DIST") == "1"      # the env knob exercises the RCCL path with one rank
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -192,6 +301,23 @@ def main():
             torch.cuda.synchronize()
             extras["traj_opts_per_s_B8192_fp32_samples"] = 8192 * 3 / (time.perf_counter() - t1)
             del o3
+        # the boundary call itself: ONE uph_optimize_batch = upload + solve + download of x and the coefficients into pageable host arrays, the
+        # reference's synchronous contract (alm_traj_opt.h:92-98, result pulled afterwards :165-168); B = the batch and B = 1
+        bo = U.ALMTrajOpt(m)
+        if args.lanes:
+            bo.set_lanes(args.lanes)
+        bd = {}
+        for tag, pp in (("B%d" % args.batch, probs), ("B1", [scenes.hill_problem()])):
+            prep = bo.prepare_boundary(pp)
+            bo.set_rho(1.0); bo.optimize_boundary(pp, prepared=prep)
+            ts = []
+            for _ in range(2 if len(pp) > 1 else 5):
+                bo.set_rho(1.0); bo.optimize_boundary(pp, prepared=prep)
+                ts.append(bo.last_boundary_s)
+            bd[tag] = {"traj_opts_per_s": len(pp) / min(ts), "ms_per_call": min(ts) * 1e3}
+        bd["note"] = "uph_optimize_batch wall clock (upload + initScaling + solve + download of x, c_xy, c_yaw), pageable host arrays, best of the repeats"
+        extras["boundary"] = bd
+        del bo
     opt.upload(probs)
 
     kernel_ms, prepare_ms, evals, sample_evals, iters, hist_bytes = [], [], 0, 0, 0, 0
@@ -205,12 +331,17 @@ def main():
         evals += st["evals"]; sample_evals += st["sample_evals"]; iters += st["lbfgs_iters"]; hist_bytes += st["hist_bytes"]
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = [dt / args.steps * 1e3]
     if distributed:
+        mine = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        allt = torch.empty(world, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(allt, mine)                      # (reporting only: outside the timed region)
+        per_rank_ms = [float(v) / args.steps * 1e3 for v in allt.tolist()]
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    out = opt.download()
+    out = opt.download(full=False)
     rets = np.array([o["ret"] for o in out])
     pipelined = None
     if args.pipelined:
@@ -247,6 +378,12 @@ def main():
         per_launch_bytes = (sample_evals * bytes_per_sample + hist_bytes + iters * 2 * 8 * (n_sum / max(1, args.batch))) / K
         avg_ms = float(np.mean(kernel_ms))
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        tr = None if km2 else pmc_traffic(args.batch, hist_bytes / K + sample_evals * 14 * 8 / K)
+        traffic, traffic_src = (tr[0], "committed rocprofv3 --pmc passes of this command (%s), not measured in this run" % tr[1]) if tr else \
+                               (None, "no committed PMC pass for this workload / batch size (profiles/pmc_traffic.json holds B = 16384 hill only)")
+        # 7 of the 47 doubles per sample are the residual stores of SURVEY.md 8d's definition, which the solve kernel performs once per L-BFGS
+        # pass, not per evaluation: the fraction without them is reported next to the defined one
+        moved_bytes = (sample_evals * (bytes_per_sample - 7 * 8) + hist_bytes + iters * 2 * 8 * (n_sum / max(1, args.batch))) / K
         res = {
             "metric": "MINCO traj-opts/sec (batch)", "value": value, "unit": "traj-opts/s", "n_gpus": world, "steps": K,
             "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if km2 else "weak",
@@ -255,15 +392,17 @@ def main():
                                     "local-goal (4-14 m) full ALM solves split over the GPUs, run_hill.yaml params" % (args.map_size, args.map_size, total_batch)) if km2 else
                                    ("hill scene (synthetic hill cloud, map built on device), batch of %d random start/goal "
                                     "full ALM solves per GPU (configs[1] scene, configs[2] start/goal protocol), run_hill.yaml params" % args.batch),
-                       "batch_per_gpu": args.batch, "grid": [nx, ny, int(m.voxel_num[2])], "parallelism": ("dp%d" % world) + (" (grid tiled by x-slab owner + 20 m halo)" if km2 and m.tile is not None else "")},
+                       "batch_per_gpu": args.batch, "grid": [nx, ny, int(m.voxel_num[2])], "launcher": "self-spawned ranks" if os.environ.get("UPH_BENCH_SPAWNED") == "1" else ("torch.distributed.run" if distributed else "single process"),
+                       "rccl_world": dist.get_world_size() if distributed else 1, "parallelism": ("dp%d" % world) + (" (grid tiled by x-slab owner + 20 m halo)" if km2 and m.tile is not None else "")},
+            "per_rank_ms_per_step": per_rank_ms,
             "ms_per_lbfgs_iter": single_ms_per_iter,       # single hill trajectory alone on the GPU (configs[1]): solve kernel ms / its L-BFGS iterations
             "single_traj_ms": single_ms, "batch_lbfgs_iters_per_s": iters / dt,
             "lbfgs_iters_per_traj": iters / K / args.batch, "evals_per_traj": evals / K / args.batch,
             "scaling_kernel_ms": float(np.mean(prepare_ms)),
             "converged_frac": float((rets == 0).mean()), "map_build_s": map_build_s, "map_kernel_ms": map_stats["kernel_ms"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if km2 else pmc_traffic(args.batch, hist_bytes / K + sample_evals * 14 * 8 / K), "kernel": "uph_solver_kernel<%s,2> (ALM/L-BFGS solve)" % ("128,2" if args.batch >= 2304 else ("256,2" if args.batch >= 512 else "256,1")), "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": per_launch_bytes,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "uph_solver_kernel<%s,2> (ALM/L-BFGS solve)" % ("128,2" if args.batch >= 2304 else ("256,2" if args.batch >= 512 else "256,1")), "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": per_launch_bytes, "frac_without_unwritten_residuals": moved_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "sample_bytes_per_launch": sample_evals * bytes_per_sample / K, "history_bytes_per_launch": hist_bytes / K},
         }
         res.update(extras)
@@ -275,7 +414,7 @@ def main():
             if not km2:
                 og = O.OracleGrid()
                 og.set_cells(m.map_buffer)
-            cdt, c_iters = 0.0, 0
+            cdt, c_iters, oref = 0.0, 0, []
             for p in probs[:nsamp]:
                 # km2: the 1e9-cell grid stays on the device; the problem is solved on the window of cells around it, translated by whole
                 # cells (window download not timed)
@@ -284,9 +423,27 @@ def main():
                 r = O.OracleALM(g_).optimize(q_)
                 cdt += time.perf_counter() - t0
                 c_iters += r["lbfgs_iters"]
+                oref.append(r)
             res["cpu_baseline"] = {"value": nsamp / cdt, "unit": "traj-opts/s", "cores": 1, "kind": "port",
                                    "sample": "first %d problems of the same batch, CPU oracle (C++ -O3, single thread), %.1f s" % (nsamp, cdt),
-                                   "ms_per_lbfgs_iter": cdt * 1e3 / max(1, c_iters), "host_cpus": os.cpu_count()}
+                                   "ms_per_lbfgs_iter": cdt * 1e3 / max(1, c_iters), "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+                                   "converged_frac": float(np.mean([r_["ret"] == 0 for r_ in oref]))}
+            # the headline's parity statement: the timed batch's own results (same inputs, rho reset every step) against the oracle on that sample,
+            # bucketed by the oracle's L-BFGS iteration count (the optimiser amplifies rounding noise ~1.25x per iteration,
+            # so <= 1e-4 on final way-points holds for short solves and decays with length -- for the oracle against its own FMA rebuild as well)
+            edges = [0, 80, 120, 180, 260, 400, 1 << 30]
+            rows = []
+            devs = out[:nsamp]
+            relx = np.array([np.abs(d_["x"] - r_["x"]).max() / max(1e-300, np.abs(r_["x"]).max()) for d_, r_ in zip(devs, oref)])
+            its = np.array([r_["lbfgs_iters"] for r_ in oref])
+            for lo_, hi_ in zip(edges[:-1], edges[1:]):
+                sel = (its >= lo_) & (its < hi_)
+                if sel.any():
+                    rows.append({"iters": [lo_, hi_ if hi_ < (1 << 30) else None], "n": int(sel.sum()), "waypoints_le_1e-4": float((relx[sel] <= 1e-4).mean()), "median": float(np.median(relx[sel]))})
+            res["parity_floor"] = {"sample": nsamp, "same_ret": float(np.mean([d_["ret"] == r_["ret"] for d_, r_ in zip(devs, oref)])),
+                                   "waypoints_le_1e-4": float((relx <= 1e-4).mean()), "converged_frac_device_on_sample": float(np.mean([d_["ret"] == 0 for d_ in devs])),
+                                   "by_oracle_lbfgs_iters": rows,
+                                   "note": "device vs CPU oracle, final way-points, relative inf-norm; the oracle rebuilt with FMA contraction shows the same decay (profiles/*parity_buckets.json)"}
             if args.cpu_threads > 1 and not km2:
                 # context only: the reference is single-threaded; this is "one trajectory per host thread" on the same box
                 from concurrent.futures import ThreadPoolExecutor

@@ -24,6 +24,9 @@
  *   uph_init_scaling_batch  <- ALMTrajOpt::initScaling  alm_traj_opt.cpp:349-661 (test hook)
  *   uph_report_batch        <- ALMTrajOpt::getMaxVxAxAyCurAttSig alm_traj_opt.h:170-229 + SE2Trajectory::getNonHolError
  *                              se2traj.hpp:551-561
+ *   uph_map_build_multi     <- UnevenMap::constructMap (as above) sharded over the GPUs of one node from ONE host process -- the reference
+ *                              is a single process (plan_manager/src/manager_node.cpp): x-slabs + one RCCL all-gather (BASELINE.json configs[3])
+ *   uph_optimize_batch_multi<- B x ALMTrajOpt::optimizeSE2Traj split over per-device contexts (BASELINE.json configs[2], [4])
  */
 #ifndef UNEVEN_HIP_H
 #define UNEVEN_HIP_H
@@ -188,6 +191,24 @@ int uph_map_get_cells(uph_map* m, double* rxs2, double* c, char* occ, char* occ_
 /* constructMap on the x-slab [x0, x1): crop box + 1 cm voxel filter on the host, plane fits on the device.
  * xyz: n x 3 float32 (what pcl::PCDReader delivers).  Cells outside the slab are untouched.  Blocking. */
 int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x1);
+/* ---- several GPUs, one host process.  maps[g] = one map per device (same parameters and storage, whole-grid maps).  Device g produces the
+ * x-slab [g per, min(nx, (g + 1) per)), per = ceil(nx / n_gpus), of the cell array -- all devices concurrently, one host thread each --, ONE
+ * ncclAllGather over an in-process RCCL clique (ncclCommInitAll; in place on the cell arrays when n_gpus divides nx) leaves the complete array
+ * on every device, every map commits.  Results are bit-identical to uph_map_build on one device.  RCCL is bound at first use (dlopen: an RCCL
+ * the process already carries, else the system's); n_gpus = 1 needs none.  maps on the SAME device are accepted (single-GPU test
+ * configuration: RCCL refuses a device twice, the slabs then move by device-to-device copies).  Blocking. */
+int uph_map_build_multi(uph_map* const* maps, int32_t n_gpus, const float* xyz, int64_t n);
+/* the analytic terrain (uph_map_fill_fbm) sharded the same way; fp32 maps exchange float slabs */
+int uph_map_fill_fbm_multi(uph_map* const* maps, int32_t n_gpus, const uph_fbm_params* fp);
+/* wall milliseconds of the last *_multi call led by `lead` (= maps[0]): slab fits, slab exchange, commit; HIP-event milliseconds of the
+ * all-gather on device 0's stream; via_rccl = 1 if the exchange was an RCCL collective */
+int uph_map_multi_stats(uph_map* lead, double* fit_ms, double* exchange_ms, double* commit_ms, double* exchange_device_ms, int32_t* via_rccl);
+/* diagnostic: binds RCCL the way the sharded build does, forms the in-process clique of devices 0 .. n_devices-1 and all-gathers a known
+ * pattern; info (may be NULL) receives which librccl was bound and its version.  UPH_OK = the collective path works in this process */
+int uph_rccl_selftest(int32_t n_devices, char* info, int32_t info_cap);
+/* releases the cached RCCL cliques (optional; they live until process exit otherwise) */
+void uph_multi_shutdown(void);
+
 /* device pointer / byte size of the AoS cell array (ncell x 4 doubles) so that the host framework can all-gather
  * x-slabs across GPUs (RCCL) in place; call uph_map_commit afterwards to refresh c and occupancy */
 int uph_map_cells_device(uph_map* m, void** dptr, int64_t* nbytes);
@@ -243,6 +264,13 @@ int uph_ctx_get_trace(uph_ctx* c, double* out);
  * the batch: its result carries ret_code UPH_RET_UNSUPPORTED and the others are solved; only a batch without any supported problem
  * returns UPH_ERR_INVALID / UPH_ERR_LIMIT. */
 int uph_optimize_batch(uph_ctx* c, int32_t B, const uph_problem* probs, uph_result* results);
+/* the same call over several GPUs of this process: ctxs[g] = one context per device (each bound to its device's copy of the map, e.g. from
+ * uph_map_build_multi).  The problems are dealt to the contexts in descending predicted cost, round-robin; one host thread per device runs
+ * upload -> solve -> download on its share; results[] comes back in the caller's order.  No collective: trajectories are independent.
+ * Contexts on the same device are accepted (test configuration).  n_gpus = 1 is uph_optimize_batch. */
+int uph_optimize_batch_multi(uph_ctx* const* ctxs, int32_t n_gpus, int32_t B, const uph_problem* probs, uph_result* results);
+/* number of problems of the uploaded batch (0: none) */
+int uph_batch_count(const uph_ctx* c);
 /* split form (inputs resident in HBM before the timed region): upload -> solve (kernel only, blocking) -> download */
 int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs);
 int uph_batch_solve(uph_ctx* c);
@@ -290,7 +318,7 @@ int uph_batch_set_lbfgs_state(uph_ctx* c, const double* g, const double* d, cons
 int uph_batch_lbfgs_resume(uph_ctx* c, int32_t budget, int32_t finish_pass);
 /* state afterwards; scal8 [B][8] = step, fx, k, end, bound, L-BFGS code (999 = budget ran out), accepted, converged */
 int uph_batch_get_lbfgs_state(uph_ctx* c, double* g, double* d, double* pf, double* lm_s, double* lm_y, double* lm_ys, double* scal8);
-/* post-solve feasibility report per trajectory: out[B][7] = max vx, ax, ay, cur, att(-cos xi), sigma, non-holonomic error */
+/* post-solve feasibility report per trajectory: out[B][7] = max vx, ax, ay, cur, att(-cos xi), sigma, non-holonomic error; B = uph_batch_count */
 int uph_report_batch(uph_ctx* c, double* out7);
 
 #ifdef __cplusplus

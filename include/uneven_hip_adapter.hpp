@@ -213,6 +213,13 @@ public:
     // fills the host members of the reference's UnevenMap (map_buffer as 4 doubles per cell, c_buffer, occ_buffer, occ_r2_buffer)
     void download(double* rxs2, double* c, char* occ, char* occ_r2) { uph_map_get_cells(m_, rxs2, c, occ, occ_r2); }
     uph_map* get() const { return m_; }
+    // constructMap over several GPUs of this process: maps[g] lives on device g; x-slab fits on all devices at once, one RCCL all-gather inside
+    // the library, every map ends up with the complete grid (uph_map_build_multi)
+    static void constructMapMulti(const std::vector<UnevenMapHandle*>& maps, const float* xyz, long n) {
+        std::vector<uph_map*> h;
+        for (UnevenMapHandle* m : maps) h.push_back(m->get());
+        if (uph_map_build_multi(h.data(), (int32_t)h.size(), xyz, n) != UPH_OK) throw std::runtime_error(std::string("uph_map_build_multi: ") + uph_last_error());
+    }
 
 private:
     uph_map* m_ = nullptr;
@@ -283,8 +290,10 @@ public:
         std::vector<SE2Trajectory> traj;
         std::vector<double> jerk_cost, total_time;
     };
+    // peers: optimisers bound to the OTHER GPUs' copies of the map (setEnvironment done); the batch is then split over this object's device
+    // and theirs (uph_optimize_batch_multi: one host thread per device, results in the caller's order)
     template <class Path>
-    BatchPlan optimizeSE2TrajBatch(const std::vector<Path>& paths, const uph_manager_params& mgr) {
+    BatchPlan optimizeSE2TrajBatch(const std::vector<Path>& paths, const uph_manager_params& mgr, const std::vector<ALMTrajOpt*>& peers = {}) {
         const int32_t B = (int32_t)paths.size(), cap_xy = 2 * UPH_MAX_PIECE_XY, cap_yaw = 2 * UPH_MAX_PIECE_YAW;
         BatchPlan out;
         if (B == 0) return out;
@@ -296,9 +305,14 @@ public:
                 for (int k = 0; k < 3; k++) flat[((size_t)off[b] + i) * 3 + k] = paths[b][i][k];
         std::vector<double> ixy((size_t)B * 6), exy((size_t)B * 6), iyw((size_t)B * 3), eyw((size_t)B * 3), oxy((size_t)B * 2 * cap_xy), oyw((size_t)B * cap_yaw), tt(B);
         std::vector<int32_t> nxy(B), nyw(B);
-        if (uph_resample_batch(&mgr, B, flat.data(), off.data(), cap_xy, cap_yaw, ixy.data(), exy.data(), iyw.data(), eyw.data(), oxy.data(), oyw.data(),
-                               nxy.data(), nyw.data(), tt.data(), nullptr) != UPH_OK)
-            throw std::runtime_error(std::string("uph_resample_batch: ") + uph_last_error());
+        const int rrc = uph_resample_batch(&mgr, B, flat.data(), off.data(), cap_xy, cap_yaw, ixy.data(), exy.data(), iyw.data(), eyw.data(), oxy.data(), oyw.data(),
+                                           nxy.data(), nyw.data(), tt.data(), nullptr);
+        if (rrc != UPH_OK && rrc != UPH_ERR_LIMIT) throw std::runtime_error(std::string("uph_resample_batch: ") + uph_last_error());
+        // UPH_ERR_LIMIT: some path needs more way-points than the buffers hold (the counts are still reported).  Such a path is far beyond
+        // the compiled piece limits anyway: clamp its counts to just above them so that the upload marks exactly that slot UNSUPPORTED and
+        // the other goals are solved (the documented contract), instead of failing the whole batch
+        for (int32_t b = 0; b < B; b++)
+            if (nxy[b] > cap_xy || nyw[b] > cap_yaw) { nxy[b] = UPH_MAX_PIECE_XY; nyw[b] = UPH_MAX_PIECE_YAW; }
         std::vector<uph_problem> pr(B);
         std::vector<uph_result> rs(B);
         std::vector<size_t> ox(B), oc(B), oy(B);
@@ -320,9 +334,11 @@ public:
             rs[b].x_final = xs.data() + ox[b]; rs[b].c_xy = cx.data() + oc[b]; rs[b].c_yaw = cy.data() + oy[b];
         }
         in_opt = true;
-        const int rc = uph_optimize_batch(ctx_, B, pr.data(), rs.data());
+        std::vector<uph_ctx*> cs(1, ctx_);
+        for (ALMTrajOpt* q : peers) cs.push_back(q->ctx_);
+        const int rc = uph_optimize_batch_multi(cs.data(), (int32_t)cs.size(), B, pr.data(), rs.data());
         in_opt = false;
-        if (rc != UPH_OK) throw std::runtime_error(std::string("uph_optimize_batch: ") + uph_last_error());
+        if (rc != UPH_OK) throw std::runtime_error(std::string("uph_optimize_batch_multi: ") + uph_last_error());
         for (int32_t b = 0; b < B; b++) {
             out.ret.push_back(rs[b].ret_code);
             out.jerk_cost.push_back(rs[b].jerk_cost);
@@ -337,9 +353,17 @@ public:
     // getMaxVxAxAyCurAttSig (alm_traj_opt.h:170-229): max vx, ax, ay, curvature, attitude (-cos xi), sigma sampled every 0.01 s -- evaluated
     // on the device for the trajectory of the last optimizeSE2Traj (the argument is what getTraj() returned for it)
     std::vector<double> getMaxVxAxAyCurAttSig(const SE2Trajectory&) {
-        double o[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (uph_report_batch(ctx_, o) != UPH_OK) throw std::runtime_error(std::string("uph_report_batch: ") + uph_last_error());
-        return std::vector<double>(o, o + 6);
+        const std::vector<double> all = getMaxVxAxAyCurAttSigBatch();     // (after optimizeSE2TrajBatch the context holds B trajectories: row 0)
+        return std::vector<double>(all.begin(), all.begin() + 6);
+    }
+    // the same report for every trajectory of the last call: [B][7] = max vx, ax, ay, cur, att, sigma, non-holonomic error (rows of
+    // UPH_RET_UNSUPPORTED problems describe a placeholder, not a path)
+    std::vector<double> getMaxVxAxAyCurAttSigBatch() {
+        const int B = uph_batch_count(ctx_);
+        if (B <= 0) throw std::runtime_error("getMaxVxAxAyCurAttSig: no trajectory has been optimised on this object");
+        std::vector<double> o((size_t)7 * B, 0.0);
+        if (uph_report_batch(ctx_, o.data()) != UPH_OK) throw std::runtime_error(std::string("uph_report_batch: ") + uph_last_error());
+        return o;
     }
     // members PlanManager calls that have no device side: rosparam loading (set the public members instead), the A* handle, RViz output
     template <class NodeHandle> void init(NodeHandle&) {}

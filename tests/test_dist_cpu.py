@@ -76,3 +76,21 @@ def test_sharded_map_build_and_batch_split(tmp_path, oracle, world):
     ref = [p["total_time"] for p in scenes.random_problems(3, seed0=1003)]
     assert np.allclose(keys[1], ref)
     assert abs(float(z["tmax"][0]) - 0.1 * world) < 1e-12                  # max over ranks
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus N` outside a launcher re-executes itself as N ranks with the torch.distributed.run environment contract
+    (bench.spawn_ranks).  The ranks are asked to echo their environment instead of touching a GPU (UPH_BENCH_SPAWN_ECHO)."""
+    import json
+    import subprocess
+    env = dict(os.environ, UPH_BENCH_SPAWN_ECHO="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["WORLD_SIZE"] == "4" and line["RANK"] == "0" and line["LOCAL_RANK"] == "0" and line["MASTER_ADDR"] == "127.0.0.1" and line["gpus"] == 4
+    # under a launcher (WORLD_SIZE set) the script does not spawn again
+    env2 = dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env2, timeout=120)
+    assert json.loads(r2.stdout.strip().splitlines()[-1])["RANK"] == "1"

@@ -75,6 +75,13 @@ SYMBOLS = {
     "uph_map_set_cells": (C.c_int, [_VP, DP]),
     "uph_map_get_cells": (C.c_int, [_VP, DP, DP, C.c_char_p, C.c_char_p]),
     "uph_map_build": (C.c_int, [_VP, C.POINTER(C.c_float), _I64, _I32, _I32]),
+    "uph_map_build_multi": (C.c_int, [C.POINTER(_VP), _I32, C.POINTER(C.c_float), _I64]),
+    "uph_map_fill_fbm_multi": (C.c_int, [C.POINTER(_VP), _I32, C.POINTER(FbmParams)]),
+    "uph_map_multi_stats": (C.c_int, [_VP, DP, DP, DP, DP, C.POINTER(_I32)]),
+    "uph_multi_shutdown": (None, []),
+    "uph_rccl_selftest": (C.c_int, [_I32, C.c_char_p, _I32]),
+    "uph_optimize_batch_multi": (C.c_int, [C.POINTER(_VP), _I32, _I32, C.POINTER(Problem), C.POINTER(Result)]),
+    "uph_batch_count": (C.c_int, [_VP]),
     "uph_map_cells_device": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I64)]),
     "uph_map_commit": (C.c_int, [_VP]),
     "uph_map_export_slab_dev": (C.c_int, [_VP, _I32, _I32, _VP]),

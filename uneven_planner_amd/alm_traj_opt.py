@@ -196,30 +196,71 @@ class ALMTrajOpt:
         _lib.check(self.L.uph_batch_cycles(self.h, out.ctypes.data_as(C.POINTER(C.c_longlong))), "uph_batch_cycles")
         return out
 
-    def download(self):
-        res = (_lib.Result * self._B)()
-        bufs = []
-        for i, sz in enumerate(self._sizes):
-            b = dict(x=np.zeros(sz["n"]), c_xy=np.zeros((6 * sz["Nxy"], 2)), c_yaw=np.zeros(6 * sz["Nyaw"]), hx=np.zeros(sz["S"]),
-                     gx=np.zeros(6 * sz["S"]), lam=np.zeros(sz["S"]), mu=np.zeros(6 * sz["S"]), scale_cx=np.zeros(7 * sz["S"]))
-            r = res[i]
-            r.x_final, r.c_xy, r.c_yaw, r.hx, r.gx = _dp(b["x"]), _dp(b["c_xy"]), _dp(b["c_yaw"]), _dp(b["hx"]), _dp(b["gx"])
-            r.lambda_, r.mu, r.scale_cx = _dp(b["lam"]), _dp(b["mu"]), _dp(b["scale_cx"])
-            bufs.append(b)
+    def download(self, full=True):
+        """full = False pulls only x and the coefficients (what a planner reads); the per-sample arrays then stay on the device"""
+        res, bufs = self._result_array(self._sizes, full)
         _lib.check(self.L.uph_batch_download(self.h, res), "uph_batch_download")
+        self._last = self._collect(res, bufs)
+        return self._last
+
+    def optimize_batch(self, probs):
+        self.upload(probs)
+        self.solve()
+        return self.download()
+
+    def _result_array(self, sizes, full):
+        """uph_result array with caller-owned output arrays: full = every array, else what a planner pulls (x, coefficients)"""
+        res = (_lib.Result * len(sizes))()
+        bufs = []
+        for i, sz in enumerate(sizes):
+            b = dict(x=np.zeros(sz["n"]), c_xy=np.zeros((6 * sz["Nxy"], 2)), c_yaw=np.zeros(6 * sz["Nyaw"]))
+            r = res[i]
+            r.x_final, r.c_xy, r.c_yaw = _dp(b["x"]), _dp(b["c_xy"]), _dp(b["c_yaw"])
+            if full:
+                b.update(hx=np.zeros(sz["S"]), gx=np.zeros(6 * sz["S"]), lam=np.zeros(sz["S"]), mu=np.zeros(6 * sz["S"]), scale_cx=np.zeros(7 * sz["S"]))
+                r.hx, r.gx, r.lambda_, r.mu, r.scale_cx = _dp(b["hx"]), _dp(b["gx"]), _dp(b["lam"]), _dp(b["mu"]), _dp(b["scale_cx"])
+            bufs.append(b)
+        return res, bufs
+
+    @staticmethod
+    def _collect(res, bufs):
         out = []
         for i, b in enumerate(bufs):
             r = res[i]
             b.update(ret=r.ret_code, alm_iters=r.alm_iters, lbfgs_iters=r.lbfgs_iters, evals=r.evals, last_lbfgs_ret=r.last_lbfgs_ret,
                      cost=r.cost, jerk_cost=r.jerk_cost, T_xy=r.piece_T_xy, T_yaw=r.piece_T_yaw, rho_final=r.rho_final, scale_fx=r.scale_fx)
             out.append(b)
-        self._last = out
         return out
 
-    def optimize_batch(self, probs):
-        self.upload(probs)
-        self.solve()
-        return self.download()
+    def prepare_boundary(self, probs, full=False):
+        arr, keep = self._make_problems(probs)
+        res, bufs = self._result_array(self._sizes, full)
+        return arr, keep, res, bufs
+
+    def optimize_boundary(self, probs, full=False, prepared=None):
+        """ONE uph_optimize_batch call -- upload + solve + download, the reference's synchronous contract (alm_traj_opt.h:92-98, result
+        pulled afterwards :165-168) -- with pageable host arrays.  prepared = prepare_boundary(probs) keeps the ctypes packing out of a
+        timed region."""
+        arr, keep, res, bufs = prepared if prepared is not None else self.prepare_boundary(probs, full)
+        self._B = 0
+        import time
+        t0 = time.perf_counter()
+        rc = self.L.uph_optimize_batch(self.h, len(probs), arr, res)
+        self.last_boundary_s = time.perf_counter() - t0
+        _lib.check(rc, "uph_optimize_batch")
+        self._B = len(probs)
+        self._last = self._collect(res, bufs)
+        return self._last
+
+    @staticmethod
+    def optimize_batch_multi(opts, probs, full=False):
+        """uph_optimize_batch_multi: one batch over the contexts `opts` (one per device), results in the caller's order"""
+        lead = opts[0]
+        arr, keep = lead._make_problems(probs)
+        res, bufs = lead._result_array(lead._sizes, full)
+        hs = (C.c_void_p * len(opts))(*[o.h for o in opts])
+        _lib.check(lead.L.uph_optimize_batch_multi(hs, len(opts), len(probs), arr, res), "uph_optimize_batch_multi")
+        return ALMTrajOpt._collect(res, bufs)
 
     # ---- the reference's entry point -------------------------------------------------------------------------------
     def optimizeSE2Traj(self, initStateXY, endStateXY, innerPtsXY, initYaw, endYaw, innerPtsYaw, totalTime):

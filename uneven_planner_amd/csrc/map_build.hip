@@ -19,12 +19,18 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/uneven_hip.h"
 #include "uph_internal.hpp"
 #include "terrain_dev.hpp"
+#include "rccl_dyn.hpp"
 
 using namespace uph;
 
@@ -42,6 +48,8 @@ struct uph_map {
     size_t scratch_cap[4] = {0, 0, 0, 0};
     double last_build_ms = 0.0, last_query_ms = 0.0;
     int64_t last_cell_iters = 0, last_cloud = 0;
+    double multi_ms[4] = {0.0, 0.0, 0.0, 0.0};      // last uph_map_*_multi led by this map: slab fits (wall), slab exchange (wall), commit (wall), exchange (HIP events, device 0)
+    int multi_rccl = 0;                             // ... and whether the exchange went through RCCL (1) or device-to-device copies (0)
 };
 
 UphDevTmp::~UphDevTmp() { if (p) hipFree(p); }
@@ -716,7 +724,9 @@ int uph_fbm_table(const uph_fbm_params* fp, double* table) {
     return UPH_OK;
 }
 
-int uph_map_fill_fbm(uph_map* m, const uph_fbm_params* fp, int32_t x0, int32_t x1) {
+static int fillSlab(uph_map* m, const uph_fbm_params* fp, int32_t x0, int32_t x1, bool commit);
+int uph_map_fill_fbm(uph_map* m, const uph_fbm_params* fp, int32_t x0, int32_t x1) { return fillSlab(m, fp, x0, x1, true); }
+static int fillSlab(uph_map* m, const uph_fbm_params* fp, int32_t x0, int32_t x1, bool commit) {
     if (!m || !checkFbm(fp)) { setError("uph_map_fill_fbm: bad arguments"); return UPH_ERR_INVALID; }
     if (x1 <= 0) { x0 = m->g.x_off; x1 = m->g.x_off + m->g.nx_hold; }
     if (x0 < m->g.x_off || x1 > m->g.x_off + m->g.nx_hold || x0 >= x1) { setError("uph_map_fill_fbm: slab outside the rows this map holds"); return UPH_ERR_INVALID; }
@@ -738,7 +748,7 @@ int uph_map_fill_fbm(uph_map* m, const uph_fbm_params* fp, int32_t x0, int32_t x
     m->last_build_ms = ms;
     m->last_cell_iters = (int64_t)(x1 - x0) * m->g.ny * m->g.nyaw * m->mp.iter_num;
     m->last_cloud = 0;
-    return commitMap(m);
+    return commit ? commitMap(m) : UPH_OK;
 }
 
 int uph_map_build_stats(uph_map* m, double* kernel_ms, int64_t* cell_iters, int64_t* cloud_points) {
@@ -749,7 +759,9 @@ int uph_map_build_stats(uph_map* m, double* kernel_ms, int64_t* cell_iters, int6
     return UPH_OK;
 }
 
-int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x1) {
+static int buildSlab(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x1, bool commit);
+int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x1) { return buildSlab(m, xyz, n, x0, x1, true); }
+static int buildSlab(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x1, bool commit) {
     if (m && m->d_cells32) { setError("uph_map_build: the plane fit writes fp64 cells; create the map with uph_map_create"); return UPH_ERR_INVALID; }
     if (!m || !xyz || n <= 0) { setError("uph_map_build: bad arguments"); return UPH_ERR_INVALID; }
     const GridDev& g = m->g;
@@ -826,7 +838,254 @@ int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x
     m->last_build_ms = ms;
     m->last_cell_iters = (int64_t)ncol * g.nyaw * m->mp.iter_num;
     m->last_cloud = (int64_t)np;
-    return commitMap(m);
+    return commit ? commitMap(m) : UPH_OK;
+}
+
+
+// ---- one grid over several GPUs of ONE process (SURVEY.md 8b "Environment", 8e row 2; BASELINE.json configs[3]) ------------------------
+// The reference is a single process (plan_manager/src/manager_node.cpp, ros::spin()), so the sharded build has to be reachable from one
+// host thread: the caller hands over one map per device, device g produces the x-slab [g per, (g+1) per) of the cell array (x is the
+// slowest index, uneven_map.h:427-435: a slab is one contiguous block) on its own host thread, ONE ncclAllGather over an in-process RCCL
+// clique (ncclCommInitAll) leaves the whole array on every device, every map commits (c, occupancy).  When nx is a multiple of the device
+// count the gather runs IN PLACE on the cell arrays (send = the slab where it lies); otherwise through zero-padded staging.
+// Cliques are cached per device list for the life of the process (creating one costs ~1 s); uph_multi_shutdown releases them.
+}  // extern "C"
+namespace {
+struct Clique {
+    std::vector<int> devs;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;
+};
+std::mutex g_clique_mu;
+std::vector<Clique*> g_cliques;
+
+Clique* getClique(const std::vector<int>& devs, const RcclApi* api, std::string& why) {
+    std::lock_guard<std::mutex> lk(g_clique_mu);
+    for (Clique* q : g_cliques) if (q->devs == devs) return q;
+    Clique* q = new Clique();
+    q->devs = devs;
+    q->comms.assign(devs.size(), nullptr);
+    const ncclResult_t r = api->CommInitAll(q->comms.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) { why = std::string("ncclCommInitAll: ") + api->GetErrorString(r); delete q; return nullptr; }
+    q->streams.assign(devs.size(), nullptr);
+    for (size_t g = 0; g < devs.size(); g++) {
+        if (hipSetDevice(devs[g]) != hipSuccess || hipStreamCreateWithFlags(&q->streams[g], hipStreamNonBlocking) != hipSuccess) { why = "hipStreamCreate for the RCCL clique failed"; return nullptr; }
+    }
+    g_cliques.push_back(q);
+    return q;
+}
+
+// slab rule shared with the host mirrors (uneven_planner_amd/uneven_map.py slab_bounds): per = ceil(nx / n)
+inline void slabOf(int nx, int g, int n, int& per, int& x0, int& x1) { per = (nx + n - 1) / n; x0 = std::min(g * per, nx); x1 = std::min(x0 + per, nx); }
+
+int checkMultiMaps(uph_map* const* maps, int n, const char* who, bool need_f64) {
+    if (!maps || n < 1) { setError(std::string(who) + ": bad arguments"); return UPH_ERR_INVALID; }
+    for (int g = 0; g < n; g++) {
+        const uph_map* m = maps[g];
+        if (!m) { setError(std::string(who) + ": null map"); return UPH_ERR_INVALID; }
+        for (int h = 0; h < g; h++) if (maps[h] == m) { setError(std::string(who) + ": the same map twice"); return UPH_ERR_INVALID; }
+        if (m->g.nx_hold != m->g.nx) { setError(std::string(who) + ": tile maps hold their own rows only (nothing to gather)"); return UPH_ERR_INVALID; }
+        if (need_f64 && m->d_cells32) { setError(std::string(who) + ": the plane fit writes fp64 cells; create the maps with uph_map_create"); return UPH_ERR_INVALID; }
+        if (m->g.nx != maps[0]->g.nx || m->g.ny != maps[0]->g.ny || m->g.nyaw != maps[0]->g.nyaw || (m->d_cells32 != nullptr) != (maps[0]->d_cells32 != nullptr) ||
+            std::memcmp(&m->mp, &maps[0]->mp, sizeof(uph_map_params)) != 0) { setError(std::string(who) + ": the maps differ in parameters or storage"); return UPH_ERR_INVALID; }
+    }
+    return UPH_OK;
+}
+
+double wallMs(std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); }
+
+// every map holds its own slab; afterwards every map holds all slabs
+int exchangeSlabs(uph_map* const* maps, int n, const char* who) {
+    uph_map* lead = maps[0];
+    const int nx = lead->g.nx;
+    const size_t row = (size_t)lead->g.ny * lead->g.nyaw * cellBytes(lead);
+    int per, a0, a1;
+    slabOf(nx, 0, n, per, a0, a1);
+    lead->multi_ms[3] = 0.0;
+    if (n == 1) { lead->multi_rccl = 0; return UPH_OK; }
+    std::vector<int> devs(n);
+    bool distinct = true;
+    for (int g = 0; g < n; g++) { devs[g] = maps[g]->device; for (int h = 0; h < g; h++) distinct &= devs[h] != devs[g]; }
+    if (!distinct) {
+        // several maps on one device: RCCL refuses a clique with a device twice.  This is the single-GPU test configuration (a "world" of
+        // slabs played on one device); the exchange is plain device-to-device copies, the slab rule and everything around it is the same.
+        lead->multi_rccl = 0;
+        for (int g = 0; g < n; g++) {
+            int x0, x1;
+            slabOf(nx, g, n, per, x0, x1);
+            if (x1 <= x0) continue;
+            for (int h = 0; h < n; h++) {
+                if (h == g) continue;
+                HIPCHK(hipMemcpyPeer(cellBase(maps[h]) + (size_t)x0 * row, maps[h]->device, cellBase(maps[g]) + (size_t)x0 * row, maps[g]->device, (size_t)(x1 - x0) * row));
+            }
+        }
+        return UPH_OK;
+    }
+    std::string why;
+    const RcclApi* api = rcclApi(why);
+    if (!api) { setError(std::string(who) + ": " + why); return UPH_ERR_HIP; }
+    Clique* q = getClique(devs, api, why);
+    if (!q) { setError(std::string(who) + ": " + why); return UPH_ERR_HIP; }
+    lead->multi_rccl = 1;
+    const bool inplace = nx % n == 0;
+    const size_t slab_bytes = (size_t)per * row;
+    const ncclDataType_t dt = lead->d_cells32 ? ncclFloat : ncclDouble;
+    const size_t count = slab_bytes / (lead->d_cells32 ? sizeof(float) : sizeof(double));
+    std::vector<UphDevTmp> stage(n);
+    if (!inplace) {
+        for (int g = 0; g < n; g++) {
+            int x0, x1;
+            slabOf(nx, g, n, per, x0, x1);
+            HIPCHK(hipSetDevice(devs[g]));
+            HIPCHK(hipMalloc(&stage[g].p, slab_bytes * n));
+            HIPCHK(hipMemsetAsync((char*)stage[g].p + (size_t)g * slab_bytes, 0, slab_bytes, q->streams[g]));
+            if (x1 > x0) HIPCHK(hipMemcpyAsync((char*)stage[g].p + (size_t)g * slab_bytes, cellBase(maps[g]) + (size_t)x0 * row, (size_t)(x1 - x0) * row, hipMemcpyDeviceToDevice, q->streams[g]));
+        }
+    }
+    UphEventTmp e0, e1;
+    HIPCHK(hipSetDevice(devs[0]));
+    HIPCHK(hipEventCreate((hipEvent_t*)&e0.e)); HIPCHK(hipEventCreate((hipEvent_t*)&e1.e));
+    HIPCHK(hipEventRecord((hipEvent_t)e0.e, q->streams[0]));
+    ncclResult_t r = api->GroupStart();
+    for (int g = 0; g < n && r == ncclSuccess; g++) {
+        char* base = inplace ? cellBase(maps[g]) : (char*)stage[g].p;
+        r = api->AllGather(base + (size_t)g * slab_bytes, base, count, dt, q->comms[g], q->streams[g]);
+    }
+    const ncclResult_t re = api->GroupEnd();
+    if (r == ncclSuccess) r = re;
+    if (r != ncclSuccess) { setError(std::string(who) + ": ncclAllGather: " + api->GetErrorString(r)); return UPH_ERR_HIP; }
+    HIPCHK(hipSetDevice(devs[0]));
+    HIPCHK(hipEventRecord((hipEvent_t)e1.e, q->streams[0]));
+    for (int g = 0; g < n; g++) {
+        HIPCHK(hipSetDevice(devs[g]));
+        if (!inplace) HIPCHK(hipMemcpyAsync(cellBase(maps[g]), stage[g].p, (size_t)nx * row, hipMemcpyDeviceToDevice, q->streams[g]));
+        HIPCHK(hipStreamSynchronize(q->streams[g]));
+    }
+    float ms = 0.f;
+    HIPCHK(hipSetDevice(devs[0]));
+    HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)e0.e, (hipEvent_t)e1.e));
+    lead->multi_ms[3] = ms;
+    for (int g = 0; g < n; g++) if (stage[g].p) { hipSetDevice(devs[g]); hipFree(stage[g].p); stage[g].p = nullptr; }
+    return UPH_OK;
+}
+
+// fits on all devices at once (one host thread each), exchange, commit
+template <class Fit>
+int multiBuild(uph_map* const* maps, int n, const char* who, Fit fit) {
+    uph_map* lead = maps[0];
+    const int nx = lead->g.nx;
+    std::vector<int> rc(n, UPH_OK);
+    std::vector<std::string> err(n);
+    auto t0 = std::chrono::steady_clock::now();
+    {
+        std::vector<std::thread> th;
+        for (int g = 0; g < n; g++) {
+            int per, x0, x1;
+            slabOf(nx, g, n, per, x0, x1);
+            if (x1 <= x0) continue;
+            th.emplace_back([&, g, x0, x1]() { rc[g] = fit(maps[g], x0, x1); if (rc[g] != UPH_OK) err[g] = uph_last_error(); });
+        }
+        for (auto& t : th) t.join();
+    }
+    for (int g = 0; g < n; g++) if (rc[g] != UPH_OK) { setError(std::string(who) + ": slab " + std::to_string(g) + ": " + err[g]); return rc[g]; }
+    lead->multi_ms[0] = wallMs(t0);
+    t0 = std::chrono::steady_clock::now();
+    const int r = exchangeSlabs(maps, n, who);
+    if (r != UPH_OK) return r;
+    lead->multi_ms[1] = wallMs(t0);
+    t0 = std::chrono::steady_clock::now();
+    {
+        std::vector<std::thread> th;
+        for (int g = 0; g < n; g++) th.emplace_back([&, g]() { rc[g] = uph_map_commit(maps[g]); if (rc[g] != UPH_OK) err[g] = uph_last_error(); });
+        for (auto& t : th) t.join();
+    }
+    for (int g = 0; g < n; g++) if (rc[g] != UPH_OK) { setError(std::string(who) + ": commit " + std::to_string(g) + ": " + err[g]); return rc[g]; }
+    lead->multi_ms[2] = wallMs(t0);
+    return UPH_OK;
+}
+}  // namespace
+extern "C" {
+
+int uph_map_build_multi(uph_map* const* maps, int32_t n_gpus, const float* xyz, int64_t n) {
+    int r = checkMultiMaps(maps, n_gpus, "uph_map_build_multi", true);
+    if (r != UPH_OK) return r;
+    if (!xyz || n <= 0) { setError("uph_map_build_multi: bad arguments"); return UPH_ERR_INVALID; }
+    return multiBuild(maps, n_gpus, "uph_map_build_multi", [&](uph_map* m, int x0, int x1) { return buildSlab(m, xyz, n, x0, x1, false); });
+}
+
+int uph_map_fill_fbm_multi(uph_map* const* maps, int32_t n_gpus, const uph_fbm_params* fp) {
+    int r = checkMultiMaps(maps, n_gpus, "uph_map_fill_fbm_multi", false);
+    if (r != UPH_OK) return r;
+    if (!checkFbm(fp)) { setError("uph_map_fill_fbm_multi: bad arguments"); return UPH_ERR_INVALID; }
+    return multiBuild(maps, n_gpus, "uph_map_fill_fbm_multi", [&](uph_map* m, int x0, int x1) { return fillSlab(m, fp, x0, x1, false); });
+}
+
+int uph_map_multi_stats(uph_map* lead, double* fit_ms, double* exchange_ms, double* commit_ms, double* exchange_device_ms, int32_t* via_rccl) {
+    if (!lead) return UPH_ERR_INVALID;
+    if (fit_ms) *fit_ms = lead->multi_ms[0];
+    if (exchange_ms) *exchange_ms = lead->multi_ms[1];
+    if (commit_ms) *commit_ms = lead->multi_ms[2];
+    if (exchange_device_ms) *exchange_device_ms = lead->multi_ms[3];
+    if (via_rccl) *via_rccl = lead->multi_rccl;
+    return UPH_OK;
+}
+
+// diagnostic: binds RCCL as the sharded build would, forms the clique of devices 0 .. n_devices-1 and all-gathers a known pattern (out of
+// place, 4096 doubles per device).  0 = every device received every block; the bound library and RCCL version go to `info`.
+int uph_rccl_selftest(int32_t n_devices, char* info, int32_t info_cap) {
+    int have = 0;
+    if (n_devices < 1 || hipGetDeviceCount(&have) != hipSuccess || have < n_devices) { setError("uph_rccl_selftest: not that many devices"); return UPH_ERR_INVALID; }
+    std::string why;
+    const RcclApi* api = rcclApi(why);
+    if (!api) { setError("uph_rccl_selftest: " + why); return UPH_ERR_HIP; }
+    std::vector<int> devs(n_devices);
+    for (int g = 0; g < n_devices; g++) devs[g] = g;
+    Clique* q = getClique(devs, api, why);
+    if (!q) { setError("uph_rccl_selftest: " + why); return UPH_ERR_HIP; }
+    int ver = 0;
+    if (api->GetVersion) api->GetVersion(&ver);
+    if (info && info_cap > 0) std::snprintf(info, (size_t)info_cap, "%s, RCCL version code %d, clique of %d", api->origin.c_str(), ver, n_devices);
+    const size_t cnt = 4096;
+    std::vector<UphDevTmp> snd(n_devices), rcv(n_devices);
+    std::vector<double> host(cnt);
+    for (int g = 0; g < n_devices; g++) {
+        HIPCHK(hipSetDevice(g));
+        HIPCHK(hipMalloc(&snd[g].p, cnt * 8)); HIPCHK(hipMalloc(&rcv[g].p, cnt * 8 * n_devices));
+        for (size_t i = 0; i < cnt; i++) host[i] = 1000.0 * g + (double)i;
+        HIPCHK(hipMemcpy(snd[g].p, host.data(), cnt * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(rcv[g].p, 0, cnt * 8 * n_devices));
+    }
+    ncclResult_t r = api->GroupStart();
+    for (int g = 0; g < n_devices && r == ncclSuccess; g++) r = api->AllGather(snd[g].p, rcv[g].p, cnt, ncclDouble, q->comms[g], q->streams[g]);
+    const ncclResult_t re = api->GroupEnd();
+    if (r == ncclSuccess) r = re;
+    if (r != ncclSuccess) { setError(std::string("uph_rccl_selftest: ncclAllGather: ") + api->GetErrorString(r)); return UPH_ERR_HIP; }
+    std::vector<double> back(cnt * n_devices);
+    for (int g = 0; g < n_devices; g++) {
+        HIPCHK(hipSetDevice(g));
+        HIPCHK(hipStreamSynchronize(q->streams[g]));
+        HIPCHK(hipMemcpy(back.data(), rcv[g].p, cnt * 8 * n_devices, hipMemcpyDeviceToHost));
+        for (int h = 0; h < n_devices; h++)
+            for (size_t i = 0; i < cnt; i++)
+                if (back[h * cnt + i] != 1000.0 * h + (double)i) { setError("uph_rccl_selftest: wrong data after the all-gather"); return UPH_ERR_HIP; }
+    }
+    for (int g = 0; g < n_devices; g++) { hipSetDevice(g); hipFree(snd[g].p); snd[g].p = nullptr; hipFree(rcv[g].p); rcv[g].p = nullptr; }
+    return UPH_OK;
+}
+
+void uph_multi_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_clique_mu);
+    std::string why;
+    const RcclApi* api = rcclApi(why);
+    for (Clique* q : g_cliques) {
+        for (size_t g = 0; g < q->devs.size(); g++) {
+            hipSetDevice(q->devs[g]);
+            if (q->streams[g]) hipStreamDestroy(q->streams[g]);
+            if (api && q->comms[g]) api->CommDestroy(q->comms[g]);
+        }
+        delete q;
+    }
+    g_cliques.clear();
 }
 
 /* the cloud the map is built from: UnevenMap::init's CropBox [-10,10]^2 x [-0.01,5] + VoxelGrid 1 cm (uneven_map.cpp:133-143) applied to

@@ -13,6 +13,7 @@
 #include <map>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/uneven_hip.h"
@@ -495,6 +496,11 @@ __global__ __launch_bounds__(NT, WPS) void uph_solver_kernel(GridDev grid, OptPa
     else sol.scalingOnly(st);
 }
 
+// upload: scale_cx = 1 (alm_traj_opt.cpp:193-203) written on the device instead of shipping 7 x sum S ones over PCIe
+__global__ void uph_fill_kernel(double* __restrict__ p, size_t n, double v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 __global__ void uph_terrain_kernel(GridDev grid, const double* __restrict__ pos, int n, double* __restrict__ values, double* __restrict__ grads) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -526,6 +532,23 @@ struct DevBuf {
         return 0;
     }
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() { return (T*)p; }
+};
+
+// grow-only pinned host staging (downloads run at the PCIe rate instead of the pageable-copy rate)
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { setError("hipHostMalloc failed"); return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() { return (T*)p; }
 };
 
@@ -568,6 +591,7 @@ struct uph_ctx {
     int trace_cap = 0;                      // requested for the next upload
     int trace_cap_up = 0;                   // what the uploaded batch's trace buffer was sized for
     std::vector<TrajState> state_host;
+    HostBuf h_x, h_cxy, h_cyaw, h_dual, h_res, h_scl;      // download staging
     // stats of the last solve
     double last_ms = 0.0, last_prepare_ms = 0.0;
     int64_t last_evals = 0, last_sample_evals = 0, last_iters = 0, last_hist_bytes = 0;
@@ -641,7 +665,7 @@ static int launchSolver(uph_ctx* c, int mode, int repeat, bool async = false, hi
     // <256,2> four waves, registers capped at 256 so that two workgroups share a CU (best throughput for large batches)
 #define UPH_LAUNCH(NTL, WPS, MODE)                                                                                                     \
     do {                                                                                                                             \
-        const size_t ldsmax = c->lds_big > c->lds_bytes ? c->lds_big : c->lds_bytes;                                                 \
+        const size_t ldsmax = 160 * 1024;   /* the opt-in ceiling, not the launch size: constant, so that contexts on other host threads never lower it under a launch */ \
         HIPCHK(hipFuncSetAttribute((const void*)uph_solver_kernel<NTL, WPS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax)); \
         HIPCHK(hipEventRecord(evb, c->stream));                                                                                   \
         BatchDev bm = bd;                                                                                                            \
@@ -668,7 +692,7 @@ static int launchSolver(uph_ctx* c, int mode, int repeat, bool async = false, hi
     } while (0)
 #define UPH_LAUNCH32(NTL, WPS, MODE)                                                                                                   \
     do {                                                                                                                             \
-        const size_t ldsmax = c->lds_big > c->lds_bytes ? c->lds_big : c->lds_bytes;                                                 \
+        const size_t ldsmax = 160 * 1024;   /* the opt-in ceiling, not the launch size: constant, so that contexts on other host threads never lower it under a launch */ \
         HIPCHK(hipFuncSetAttribute((const void*)uph_solver_kernel<NTL, WPS, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax)); \
         HIPCHK(hipEventRecord(evb, c->stream));                                                                                   \
         BatchDev bm = bd;                                                                                                            \
@@ -775,6 +799,8 @@ void uph_ctx_destroy(uph_ctx* c) {
     DevBuf* bufs[] = {&c->d_ops, &c->d_desc, &c->d_state, &c->d_x, &c->d_gout, &c->d_dual, &c->d_res, &c->d_scl, &c->d_cxy, &c->d_cyaw,
                       &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas, &c->d_rsd, &c->d_rs, &c->d_gridmem, &c->d_parammem};
     for (DevBuf* b : bufs) b->release();
+    HostBuf* hbufs[] = {&c->h_x, &c->h_cxy, &c->h_cyaw, &c->h_dual, &c->h_res, &c->h_scl};
+    for (HostBuf* b : hbufs) b->release();
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -803,10 +829,23 @@ int uph_ctx_get_rho(uph_ctx* c, double* rho) { if (!c || !rho) return UPH_ERR_IN
 // diagnostic: keep the first `cap` entries of every trajectory's cost trace (0 = off); read back with uph_ctx_get_trace
 int uph_ctx_set_trace(uph_ctx* c, int32_t cap) { if (!c || cap < 0) return UPH_ERR_INVALID; c->trace_cap = cap; return UPH_OK; }
 int uph_ctx_get_trace(uph_ctx* c, double* out /* B x cap */) {
+    if (c && c->pending) { setError("an asynchronous solve is in flight on this context: call uph_batch_wait first"); return UPH_ERR_INVALID; }
     if (!c || !out || c->trace_cap_up <= 0 || c->B <= 0) return UPH_ERR_INVALID;
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     HIPCHK(hipMemcpy(out, c->d_trace.p, sizeof(double) * (size_t)c->B * c->trace_cap_up, hipMemcpyDeviceToHost));
     return UPH_OK;
+}
+
+// a-priori cost of one solve (relative units): the launch order inside a batch and the split of a batch over several GPUs use it
+static double predictedCost(const uph_problem& pr) {
+    double turn = 0.0, kink = 0.0, prev = pr.init_yaw[0];
+    for (int i = 0; i <= pr.n_inner_yaw; i++) {
+        const double cur = i < pr.n_inner_yaw ? pr.inner_yaw[i] : pr.end_yaw[0];
+        const double dy = std::fabs(cur - prev);
+        turn += dy; kink = std::max(kink, dy); prev = cur;
+    }
+    const double n = 2.0 * pr.n_inner_xy + pr.n_inner_yaw + 1.0;
+    return std::pow(n, 0.831) * std::exp(0.129 * turn) * std::pow(1.0 + kink, 0.408);
 }
 
 int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
@@ -825,9 +864,10 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     c->lanes = c->lanes_forced ? c->lanes_forced : (B >= 2304 ? 128 : (B <= 256 ? 512 : 256));      // up to one trajectory per CU: eight waves each (shortest latency)
     c->wps = c->wps_forced ? c->wps_forced : ((B >= 512) ? 2 : 1);
     c->fp_bytes.assign(B, 0);
-    // A problem outside the compiled limits (no inner way-point in a block: a goal closer than one piece length; more pieces than
-    // UPH_MAX_PIECE_*; fewer yaw pieces than position pieces) does not fail its neighbours: a two-piece placeholder takes its slot and
-    // its result carries ret_code UPH_RET_UNSUPPORTED.  Only a batch with no supported problem at all is an error.
+    // A problem outside the compiled limits (more pieces than UPH_MAX_PIECE_*; fewer yaw pieces than position pieces; on a tile map a
+    // path outside the tile) does not fail its neighbours: a two-piece placeholder takes its slot and its result carries ret_code
+    // UPH_RET_UNSUPPORTED.  Only a batch with no supported problem at all is an error.  (A goal closer than one piece length -- a single
+    // quintic per block, no inner way-point -- IS solved, as the reference solves it.)
     static const double ph_inner_xy[2] = {0.3, 0.0}, ph_inner_yaw[1] = {0.0};
     uph_problem placeholder;
     std::memset(&placeholder, 0, sizeof(placeholder));
@@ -905,16 +945,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     // affects results.  (Tried and dropped: cutting the sorted list into per-XCD chunks for L2 locality -- 8 % slower.)
     {
         std::vector<double> cost(B);
-        for (int b = 0; b < B; b++) {
-            const uph_problem& pr = *pp[b];
-            double turn = 0.0, kink = 0.0, prev = pr.init_yaw[0];
-            for (int i = 0; i <= pr.n_inner_yaw; i++) {
-                const double cur = i < pr.n_inner_yaw ? pr.inner_yaw[i] : pr.end_yaw[0];
-                const double dy = std::fabs(cur - prev);
-                turn += dy; kink = std::max(kink, dy); prev = cur;
-            }
-            cost[b] = std::pow((double)c->desc[b].n, 0.831) * std::exp(0.129 * turn) * std::pow(1.0 + kink, 0.408);
-        }
+        for (int b = 0; b < B; b++) cost[b] = predictedCost(*pp[b]);
         c->order.resize(B);
         std::iota(c->order.begin(), c->order.end(), 0);
         std::stable_sort(c->order.begin(), c->order.end(), [&](int a, int b2) { return cost[a] > cost[b2]; });
@@ -942,8 +973,9 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     HIPCHK(hipMemset(c->d_hist.p, 0, 8 * oh));          // the pads of the history rows must be (and stay) zero
     HIPCHK(hipMemset(c->d_dual.p, 0, 8 * 7 * os));
     HIPCHK(hipMemset(c->d_res.p, 0, 8 * 7 * os));
-    std::vector<double> ones(7 * os, 1.0);
-    HIPCHK(hipMemcpy(c->d_scl.p, ones.data(), 8 * 7 * os, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(uph_fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_scl.as<double>(), (size_t)7 * os, 1.0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
     if (c->trace_cap > 0) HIPCHK(hipMemset(c->d_trace.p, 0, 8 * (size_t)c->trace_cap * B));
     c->trace_cap_up = c->trace_cap;
     c->B = B;
@@ -965,9 +997,9 @@ int uph_batch_solve_async(uph_ctx* c) {
     for (int b = 0; b < c->B; b++) { std::memset(&c->state_host[b], 0, sizeof(TrajState)); c->state_host[b].rho = c->rho; c->state_host[b].scale_fx = 1.0; }
     HIPCHK(hipMemcpyAsync(c->d_state.p, c->state_host.data(), sizeof(TrajState) * c->B, hipMemcpyHostToDevice, c->stream));
     int r = launchSolver(c, 1, 1, true, c->evp0, c->evp1);      // reset + initScaling (alm_traj_opt.cpp:193-203, 231-232)
-    if (r != UPH_OK) return r;
+    if (r != UPH_OK) { hipStreamSynchronize(c->stream); return r; }      // (whatever part of it was queued is drained: the context stays usable)
     r = launchSolver(c, 2, 0, true, c->ev0, c->ev1);            // ALM loop (alm_traj_opt.cpp:234-271)
-    if (r != UPH_OK) return r;
+    if (r != UPH_OK) { hipStreamSynchronize(c->stream); if (c->stream2) hipStreamSynchronize(c->stream2); return r; }
     c->pending = true;
     return UPH_OK;
 }
@@ -1002,6 +1034,8 @@ int uph_batch_solve(uph_ctx* c) {
     return r != UPH_OK ? r : uph_batch_wait(c);
 }
 
+int uph_batch_count(const uph_ctx* c) { return c ? c->B : UPH_ERR_INVALID; }
+
 int uph_batch_stats(uph_ctx* c, double* kernel_ms, int64_t* evals, int64_t* sample_evals, int64_t* lbfgs_iters, int64_t* hist_bytes) {
     if (!c) return UPH_ERR_INVALID;
     if (kernel_ms) *kernel_ms = c->last_ms;
@@ -1031,13 +1065,27 @@ int uph_batch_download(uph_ctx* c, uph_result* results) {
     const GridDev tg = uphMapGrid(c->map);
     const bool tiled = tg.nx_hold < tg.nx;
     const double tile_lo = tg.origin[0] + tg.x_off * tg.xy_res, tile_hi = tg.origin[0] + (tg.x_off + tg.nx_hold) * tg.xy_res;
-    std::vector<double> x(c->sum_n), cxy(c->sum_cxy), cyaw(c->sum_cyaw), dual(7 * c->sum_S), res(7 * c->sum_S), scl(7 * c->sum_S);
-    HIPCHK(hipMemcpy(x.data(), c->d_x.p, 8 * c->sum_n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(cxy.data(), c->d_cxy.p, 8 * c->sum_cxy, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(cyaw.data(), c->d_cyaw.p, 8 * c->sum_cyaw, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(dual.data(), c->d_dual.p, 8 * 7 * c->sum_S, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(res.data(), c->d_res.p, 8 * 7 * c->sum_S, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(scl.data(), c->d_scl.p, 8 * 7 * c->sum_S, hipMemcpyDeviceToHost));
+    // only what the caller asked for crosses PCIe: the per-sample arrays (duals, residuals, scales) are 3 x 7 x sum S doubles -- 1 GB at
+    // B = 16384 -- and a planner that pulls trajectories (alm_traj_opt.h:165-168) passes NULL for all of them
+    bool want_x = tiled, want_cxy = false, want_cyaw = false, want_dual = false, want_res = false, want_scl = false;
+    for (int b = 0; b < c->B; b++) {
+        const uph_result& o = results[b];
+        if (c->rejected[b]) continue;
+        want_x |= o.x_final != nullptr; want_cxy |= o.c_xy != nullptr; want_cyaw |= o.c_yaw != nullptr;
+        want_dual |= o.lambda != nullptr || o.mu != nullptr; want_res |= o.hx != nullptr || o.gx != nullptr; want_scl |= o.scale_cx != nullptr;
+    }
+    struct Pull { bool want; HostBuf* h; DevBuf* d; size_t bytes; };
+    const Pull pulls[6] = {{want_x, &c->h_x, &c->d_x, (size_t)8 * c->sum_n}, {want_cxy, &c->h_cxy, &c->d_cxy, (size_t)8 * c->sum_cxy},
+                           {want_cyaw, &c->h_cyaw, &c->d_cyaw, (size_t)8 * c->sum_cyaw}, {want_dual, &c->h_dual, &c->d_dual, (size_t)8 * 7 * c->sum_S},
+                           {want_res, &c->h_res, &c->d_res, (size_t)8 * 7 * c->sum_S}, {want_scl, &c->h_scl, &c->d_scl, (size_t)8 * 7 * c->sum_S}};
+    for (const Pull& q : pulls) {
+        if (!q.want) continue;
+        if (q.h->ensure(q.bytes)) return UPH_ERR_HIP;
+        HIPCHK(hipMemcpyAsync(q.h->p, q.d->p, q.bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const double *x = c->h_x.as<double>(), *cxy = c->h_cxy.as<double>(), *cyaw = c->h_cyaw.as<double>(), *dual = c->h_dual.as<double>(),
+                 *res = c->h_res.as<double>(), *scl = c->h_scl.as<double>();
     for (int b = 0; b < c->B; b++) {
         const TrajDesc& t = c->desc[b];
         const TrajState& s = c->state_host[b];
@@ -1050,17 +1098,18 @@ int uph_batch_download(uph_ctx* c, uph_result* results) {
         o.ret_code = s.ret_code; o.alm_iters = s.alm_iters; o.lbfgs_iters = s.lbfgs_iters; o.evals = s.evals; o.last_lbfgs_ret = s.last_lbfgs_ret;
         o.cost = s.f; o.jerk_cost = s.jerk_cost; o.piece_T_xy = s.T_xy; o.piece_T_yaw = s.T_yaw; o.rho_final = s.rho; o.scale_fx = s.scale_fx;
         if (tiled) {                     // lookups outside the held rows were clamped to the tile: such a result is not the whole grid's
-            const double* xf = x.data() + t.off_x;
+            const double* xf = x + t.off_x;
             for (int i = 0; i < t.Nxy - 1; i++)
                 if ((tg.x_off > 0 && xf[1 + 2 * i] < tile_lo + 2.0 * tg.xy_res) || (tg.x_off + tg.nx_hold < tg.nx && xf[1 + 2 * i] > tile_hi - 2.0 * tg.xy_res)) o.ret_code = UPH_RET_LEFT_TILE;
         }
-        if (o.x_final) std::memcpy(o.x_final, x.data() + t.off_x, 8 * t.n);
-        if (o.c_xy) std::memcpy(o.c_xy, cxy.data() + t.off_cxy, 8 * 12 * t.Nxy);
-        if (o.c_yaw) std::memcpy(o.c_yaw, cyaw.data() + t.off_cyaw, 8 * 6 * t.Nyaw);
+        if (o.x_final) std::memcpy(o.x_final, x + t.off_x, 8 * t.n);
+        if (o.c_xy) std::memcpy(o.c_xy, cxy + t.off_cxy, 8 * 12 * t.Nxy);
+        if (o.c_yaw) std::memcpy(o.c_yaw, cyaw + t.off_cyaw, 8 * 6 * t.Nyaw);
+        if (!o.lambda && !o.mu && !o.hx && !o.gx && !o.scale_cx) continue;
         const int S = t.S;
-        const double* dl = dual.data() + 7 * t.off_s;
-        const double* rs = res.data() + 7 * t.off_s;
-        const double* sc = scl.data() + 7 * t.off_s;
+        const double* dl = want_dual ? dual + 7 * t.off_s : nullptr;
+        const double* rs = want_res ? res + 7 * t.off_s : nullptr;
+        const double* sc = want_scl ? scl + 7 * t.off_s : nullptr;
         for (int i = 0; i < S; i++) {
             if (o.lambda) o.lambda[i] = dl[i];
             if (o.hx) o.hx[i] = rs[i];
@@ -1082,7 +1131,67 @@ int uph_optimize_batch(uph_ctx* c, int32_t B, const uph_problem* probs, uph_resu
     return uph_batch_download(c, results);
 }
 
+// ---- one batch over several GPUs of this process (independent trajectories, replicated grid, no collective) --------
+// Problems are dealt to the contexts in descending predicted cost, round-robin, so every device gets the same mix of long and short
+// solves; one host thread per device runs upload -> solve -> download on its share (the calls block, the devices run concurrently).
+int uph_optimize_batch_multi(uph_ctx* const* ctxs, int32_t n_gpus, int32_t B, const uph_problem* probs, uph_result* results) {
+    if (!ctxs || n_gpus < 1 || B <= 0 || !probs || !results) { setError("uph_optimize_batch_multi: bad arguments"); return UPH_ERR_INVALID; }
+    for (int g = 0; g < n_gpus; g++) {
+        if (!ctxs[g]) { setError("uph_optimize_batch_multi: null context"); return UPH_ERR_INVALID; }
+        for (int h = 0; h < g; h++) if (ctxs[h] == ctxs[g]) { setError("uph_optimize_batch_multi: the same context twice"); return UPH_ERR_INVALID; }
+    }
+    if (n_gpus == 1) return uph_optimize_batch(ctxs[0], B, probs, results);
+    std::vector<int> idx(B);
+    std::iota(idx.begin(), idx.end(), 0);
+    {
+        std::vector<double> cost(B);
+        for (int b = 0; b < B; b++) {
+            const uph_problem& q = probs[b];
+            const bool readable = q.n_inner_xy >= 0 && q.n_inner_yaw >= 0 && (q.n_inner_yaw == 0 || q.inner_yaw);
+            cost[b] = readable ? predictedCost(q) : 0.0;      // (an invalid problem is rejected by its context's upload; it needs no balancing)
+        }
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b2) { return cost[a] > cost[b2]; });
+    }
+    std::vector<std::vector<int>> share(n_gpus);
+    for (int k = 0; k < B; k++) share[k % n_gpus].push_back(idx[k]);
+    for (auto& sh : share) std::sort(sh.begin(), sh.end());      // inside a share: the caller's order (the upload sorts by cost itself)
+    std::vector<int> rc(n_gpus, UPH_OK);
+    std::vector<std::string> err(n_gpus);
+    std::vector<std::vector<uph_problem>> pg(n_gpus);
+    std::vector<std::vector<uph_result>> rg(n_gpus);
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_gpus; g++) {
+        if (share[g].empty()) continue;
+        for (int b : share[g]) { pg[g].push_back(probs[b]); rg[g].push_back(results[b]); }      // shallow: the arrays stay the caller's
+        th.emplace_back([&, g]() {
+            rc[g] = uph_optimize_batch(ctxs[g], (int32_t)pg[g].size(), pg[g].data(), rg[g].data());
+            if (rc[g] != UPH_OK) err[g] = g_last_error;      // (thread-local in the worker)
+        });
+    }
+    for (auto& t : th) t.join();
+    // a share whose problems are ALL unsupported fails like a batch of its own would; the other shares' results stand.  The call reports
+    // an error only if no problem at all could be solved -- the contract of uph_optimize_batch.
+    int solved_shares = 0, first_bad = -1;
+    for (int g = 0; g < n_gpus; g++) {
+        if (share[g].empty()) continue;
+        if (rc[g] == UPH_OK) {
+            solved_shares++;
+            for (size_t k = 0; k < share[g].size(); k++) results[share[g][k]] = rg[g][k];
+        } else if (rc[g] == UPH_ERR_INVALID || rc[g] == UPH_ERR_LIMIT) {
+            if (first_bad < 0) first_bad = g;
+            for (size_t k = 0; k < share[g].size(); k++) {
+                uph_result& o = results[share[g][k]];
+                o.ret_code = UPH_RET_UNSUPPORTED; o.alm_iters = o.lbfgs_iters = o.evals = 0; o.last_lbfgs_ret = rc[g];
+                o.cost = o.jerk_cost = o.piece_T_xy = o.piece_T_yaw = 0.0; o.scale_fx = 1.0; o.rho_final = ctxs[g]->rho;
+            }
+        } else { setError("uph_optimize_batch_multi: device share " + std::to_string(g) + ": " + err[g]); return rc[g]; }
+    }
+    if (!solved_shares) { setError("uph_optimize_batch_multi: " + err[first_bad]); return rc[first_bad]; }
+    return UPH_OK;
+}
+
 int uph_batch_set_state(uph_ctx* c, const double* lambda, const double* mu, const double* scale_cx, const double* scale_fx, const double* rho) {
+    if (c && c->pending) { setError("an asynchronous solve is in flight on this context: call uph_batch_wait first"); return UPH_ERR_INVALID; }
     if (c && c->n_rejected) { setError("packed-array hooks need a batch without unsupported problems (uph_result.ret_code == UPH_RET_UNSUPPORTED)"); return UPH_ERR_INVALID; }
     if (!c || c->B <= 0) { setError("uph_batch_set_state: no batch uploaded"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
@@ -1165,6 +1274,7 @@ static void collectSolveStats(uph_ctx* c) {
     }
 }
 int uph_batch_set_x(uph_ctx* c, const double* x_packed) {
+    if (c && c->pending) { setError("an asynchronous solve is in flight on this context: call uph_batch_wait first"); return UPH_ERR_INVALID; }
     if (c && c->n_rejected) { setError("packed-array hooks need a batch without unsupported problems (uph_result.ret_code == UPH_RET_UNSUPPORTED)"); return UPH_ERR_INVALID; }
     if (!c || c->B <= 0 || !x_packed) { setError("uph_batch_set_x: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(c->device));
@@ -1186,6 +1296,7 @@ int uph_batch_alm_passes(uph_ctx* c, int32_t max_passes) {
 // as the reference holds it -- lm_s / lm_y column j of trajectory b at hist[off_b + j*n] with off_b = mem * sum_{b' < b} n_b', lm_ys
 // [B][mem] --; scal5 [B][5] = step, fx, k, end, bound.  x is the resident x (uph_batch_set_x).
 int uph_batch_set_lbfgs_state(uph_ctx* c, const double* g, const double* d, const double* pf, const double* lm_s, const double* lm_y, const double* lm_ys, const double* scal5) {
+    if (c && c->pending) { setError("an asynchronous solve is in flight on this context: call uph_batch_wait first"); return UPH_ERR_INVALID; }
     if (c && c->n_rejected) { setError("packed-array hooks need a batch without unsupported problems (uph_result.ret_code == UPH_RET_UNSUPPORTED)"); return UPH_ERR_INVALID; }
     if (!c || c->B <= 0 || !g || !d || !pf || !lm_s || !lm_y || !lm_ys || !scal5) { setError("uph_batch_set_lbfgs_state: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(c->device));
@@ -1228,6 +1339,7 @@ int uph_batch_lbfgs_resume(uph_ctx* c, int32_t budget, int32_t finish_pass) {
 // the state after uph_batch_lbfgs_resume, same layout; scal8 [B][8] = step, fx, k, end, bound, L-BFGS code (999 = budget ran out),
 // accepted, converged.  x / hx / gx / duals / rho through uph_batch_download.
 int uph_batch_get_lbfgs_state(uph_ctx* c, double* g, double* d, double* pf, double* lm_s, double* lm_y, double* lm_ys, double* scal8) {
+    if (c && c->pending) { setError("an asynchronous solve is in flight on this context: call uph_batch_wait first"); return UPH_ERR_INVALID; }
     if (!c || c->B <= 0 || !c->d_rs.p) { setError("uph_batch_get_lbfgs_state: no state set"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(c->device));
     const int mem = c->P.mem_size;

@@ -297,6 +297,39 @@ class UnevenMap:
         _lib.check(self.L.uph_map_commit(self.h), "uph_map_commit")
         self.map_ready = True
 
+    # ---- several GPUs, ONE process: the C-ABI's own sharded build (uph_map_build_multi: host threads + RCCL clique inside the library) ----
+    @staticmethod
+    def _handles(maps):
+        arr = (C.c_void_p * len(maps))(*[m.h for m in maps])
+        return arr
+
+    @staticmethod
+    def build_multi(maps, xyz, download=True):
+        """constructMap over len(maps) devices from this one process: maps[g] fits the x-slab slab_bounds(nx, g, n), ONE ncclAllGather inside
+        the library, every map commits.  Returns the stage timings of uph_map_multi_stats."""
+        L = maps[0].L
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        _lib.check(L.uph_map_build_multi(UnevenMap._handles(maps), len(maps), xyz.ctypes.data_as(C.POINTER(C.c_float)), xyz.shape[0]), "uph_map_build_multi")
+        return UnevenMap._after_multi(maps, download)
+
+    @staticmethod
+    def fill_fbm_multi(maps, fbm=None, download=True):
+        L = maps[0].L
+        fp = _fbm(fbm)
+        _lib.check(L.uph_map_fill_fbm_multi(UnevenMap._handles(maps), len(maps), C.byref(fp)), "uph_map_fill_fbm_multi")
+        return UnevenMap._after_multi(maps, download)
+
+    @staticmethod
+    def _after_multi(maps, download):
+        for m in maps:
+            if download:
+                m.download()
+            m.map_ready = True
+        v = [C.c_double(0) for _ in range(4)]
+        r = C.c_int32(0)
+        _lib.check(maps[0].L.uph_map_multi_stats(maps[0].h, *[C.byref(x) for x in v], C.byref(r)), "uph_map_multi_stats")
+        return dict(fit_ms=v[0].value, exchange_ms=v[1].value, commit_ms=v[2].value, exchange_device_ms=v[3].value, via_rccl=bool(r.value))
+
     # ---- `.map` text cache (uneven_map.cpp:270-315, 400-412) ------------------------------------------------------
     def write_map_file(self, path):
         """CSV `x,y,yaw,z,sigma,zbx,zby`, default ostream precision (6 significant digits) like the reference."""
