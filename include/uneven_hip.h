@@ -111,6 +111,13 @@ typedef struct uph_manager_params {
     double init_time_times;     /* 1.2  */
     double yaw_piece_times;     /* 2.0  */
     double init_sig_vel;        /* 0.05 */
+    /* test_mode != 0 selects the OTHER producer of optimizeSE2Traj's arguments in the reference, the back-end's stand-alone test node
+     * ALMTrajOpt::rcvWpsCallBack (back_end/src/alm_traj_opt.cpp:73-144): its literals replace the five parameters above (piece_len 0.3, yaw
+     * pitch piece_len / 2, end velocities 0.05, total time = length / max_vel * 1.2 with the optimiser's max_vel), each comb emits AT MOST ONE
+     * node per path segment (`if`, :122,128, where PlanManager loops with `while`), and every position node also contributes its interpolated
+     * yaw to the yaw way-points (:132).  Zero-initialised aggregates ({0.3, 0.5, 1.2, 2.0, 0.05}) keep selecting PlanManager's stage. */
+    int32_t test_mode;          /* 0    */
+    double test_max_vel;        /* ALMTrajOpt::max_vel, run_hill.yaml:35 (0.5); read in test mode only */
 } uph_manager_params;
 
 /* ---- one optimizeSE2Traj call.  Matrices are column-major like Eigen::MatrixXd:
@@ -152,7 +159,8 @@ const char* uph_last_error(void);
 int uph_device_count(void);
 const char* uph_version(void);
 
-/* ---- initial guess: PlanManager::rcvWpsCallBack between kino_astar->plan and traj_opt.optimizeSE2Traj (plan_manager.cpp:62-132), for a
+/* ---- initial guess: PlanManager::rcvWpsCallBack between kino_astar->plan and traj_opt.optimizeSE2Traj (plan_manager.cpp:62-132) -- or, with
+ *      mp->test_mode, the test node's ALMTrajOpt::rcvWpsCallBack (alm_traj_opt.cpp:73-144) --, for a
  *      batch of front-end paths.  paths = concatenated poses [x, y, yaw]; path b is poses offsets[b] .. offsets[b+1]-1.  Outputs are the
  *      optimizeSE2Traj arguments in uph_problem's layout, problem b at init_xy + 6b, init_yaw + 3b, inner_xy + 2*cap_xy*b ([x0,y0,x1,y1,..]),
  *      inner_yaw + cap_yaw*b; n_inner_* receive the way-point counts.  unwrapped (may be NULL) receives the yaw column after :62-78.

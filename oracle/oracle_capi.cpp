@@ -428,7 +428,9 @@ void orc_resample(const double* path, int M, const double* mp5, double* init_xy,
                   int cap_xy, int cap_yaw, int* n2, double* total_time, double* unwrapped) {
     orc::ManagerParams mp;
     mp.piece_len = mp5[0]; mp.mean_vel = mp5[1]; mp.init_time_times = mp5[2]; mp.yaw_piece_times = mp5[3]; mp.init_sig_vel = mp5[4];
-    orc::Resampled r = orc::resamplePath(std::vector<double>(path, path + 3 * (size_t)M), mp);
+    // mp5[1] < 0 selects the test node's stage (alm_traj_opt.cpp:73-144) with max_vel = -mp5[1]
+    orc::Resampled r = mp5[1] < 0.0 ? orc::resamplePathTest(std::vector<double>(path, path + 3 * (size_t)M), -mp5[1])
+                                    : orc::resamplePath(std::vector<double>(path, path + 3 * (size_t)M), mp);
     for (int k = 0; k < 6; k++) { init_xy[k] = r.init_xy[k]; end_xy[k] = r.end_xy[k]; }
     for (int k = 0; k < 3; k++) { init_yaw[k] = r.init_yaw[k]; end_yaw[k] = r.end_yaw[k]; }
     n2[0] = (int)(r.inner_xy.size() / 2); n2[1] = (int)r.inner_yaw.size();

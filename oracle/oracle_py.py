@@ -463,6 +463,8 @@ def resample(path, params=None):
     if params:
         q.update(params)
     mp5 = np.array([q["piece_len"], q["mean_vel"], q["init_time_times"], q["yaw_piece_times"], q["init_sig_vel"]])
+    if q.get("test_mode"):        # the back-end test node's stage (alm_traj_opt.cpp:73-144): literals + the optimiser's max_vel
+        mp5[1] = -float(q.get("test_max_vel", 0.5))
     path = _f64(path).reshape(-1, 3)
     M = path.shape[0]
     cap = 4096

@@ -83,3 +83,43 @@ def test_capacity_overflow_is_reported_with_counts(oracle):
     assert same(R.resample_batch([p], cap_xy=128, cap_yaw=256)[0], oracle.resample(p))
     with pytest.raises(_lib.UnevenHipError):
         R.resample_batch([p[:1]])                                                      # a path needs two poses
+
+
+def test_test_node_variant_three_forms_and_known_answers(oracle):
+    """the OTHER producer of optimizeSE2Traj's arguments in the reference: the back-end test node's ALMTrajOpt::rcvWpsCallBack
+    (back_end/src/alm_traj_opt.cpp:73-144) -- literals 0.3 / 2.0 / 0.05 / 1.2, the optimiser's max_vel, `if` instead of `while` in both combs,
+    every position node also appended to the yaw nodes -- selected by uph_manager_params.test_mode"""
+    ps = paths(40, 7)
+    kw = dict(test_mode=1, test_max_vel=0.7, piece_len=9.0, init_sig_vel=3.0, yaw_piece_times=7.0)      # the manager parameters must be ignored in this mode
+    native = R.resample_batch(ps, cap_xy=4096, cap_yaw=4096, **kw)
+    for p, nat in zip(ps, native):
+        assert same(oracle.resample(p, dict(test_mode=1, test_max_vel=0.7)), nat) and same(R.resample_path(p, test_mode=True, test_max_vel=0.7), nat)
+    # known answer in exact rational arithmetic: straight line along x in eleven steps of 0.22 m (no comb ever lands within 0.02 m of a
+    # threshold, so float rounding cannot flip a comparison), yaw linear in x (0.4 rad / m).  Yaw comb (pitch 0.15): every 0.22 m segment
+    # passes it, but `if` emits ONE node and the excess carries over, so node k sits at arc length 0.15 (k + 1) -- behind its own segment from
+    # k = 2 on (negative fraction: the reference extrapolates).  Position comb (pitch 0.3): fires on segments 1, 2, 4, 5, 6, 8, 9, 10 at
+    # x = 0.3, 0.6, ..., 2.4; each of these appends its yaw AFTER the yaw comb's node of the same segment.
+    from fractions import Fraction as Fr
+    step, pitch_p, pitch_y = Fr(22, 100), Fr(3, 10), Fr(15, 100)
+    cy = cp = Fr(0)
+    ex_xy, ex_yaw = [], []
+    for k in range(11):
+        cy += step; cp += step
+        if cy > pitch_y:
+            ex_yaw.append(Fr(4, 10) * (k * step + (1 - (cy - pitch_y) / step) * step)); cy -= pitch_y
+        if cp > pitch_p:
+            x = k * step + (1 - (cp - pitch_p) / step) * step
+            ex_xy.append(x); ex_yaw.append(Fr(4, 10) * x); cp -= pitch_p
+    assert [float(v) for v in ex_xy] == [0.3 * k for k in range(1, 9)] or np.allclose([float(v) for v in ex_xy], 0.3 * np.arange(1, 9))
+    assert len(ex_yaw) == 19
+    p = np.column_stack([0.22 * np.arange(12), np.zeros(12), 0.4 * 0.22 * np.arange(12)])
+    for r in (oracle.resample(p, dict(test_mode=1)), R.resample_batch([p], test_mode=1)[0], R.resample_path(p, test_mode=True)):
+        assert np.allclose(r["inner_xy"][0], [float(v) for v in ex_xy], atol=1e-12) and not r["inner_xy"][1].any()
+        assert np.allclose(r["inner_yaw"], [float(v) for v in ex_yaw], atol=1e-12)
+        assert abs(r["total_time"] - 11 * 0.22 / 0.5 * 1.2) < 1e-12
+        assert np.array_equal(r["init_xy"], [[0.0, 0.05, 0.0], [0.0, 0.0, 0.0]])
+    # a long jump (1.0 m in one segment): PlanManager's `while` emits three position nodes inside it, the test node's `if` only one and
+    # carries 0.7 on -- the two stages are different functions of the same path
+    p = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [1.1, 0.0, 0.0]])
+    assert R.resample_path(p)["inner_xy"].shape[1] == 3 and R.resample_path(p, test_mode=True)["inner_xy"].shape[1] == 2
+    assert same(oracle.resample(p, dict(test_mode=1)), R.resample_batch([p], test_mode=1)[0])

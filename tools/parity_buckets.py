@@ -4,7 +4,8 @@ For N random hill-cloud problems and a few parameter sets (the shipped run_hill.
 per ALM pass, which yields short solves), three solvers run on identical inputs: the CPU oracle, the same oracle rebuilt with FMA
 contraction (the reference's own reproducibility floor: ~1 ulp per operation, nothing else changed) and the device.  Rows = buckets
 of the oracle's total L-BFGS iteration count; columns = fraction of problems whose final way-points / cost agree with the oracle
-to 1e-4 (relative, infinity norm) and the median deviation.  usage: python tools/parity_buckets.py [N] [out.json]"""
+to 1e-4 (relative, infinity norm) and the median deviation.  usage: python tools/parity_buckets.py [N] [out.json] [hill|desert|vocano]
+(desert / vocano: the reference's own clouds, fixtures tests/golden/*_xyz.npz, run_hill.yaml / run_vocano.yaml parameters only)"""
 import json
 import os
 import sys
@@ -24,8 +25,15 @@ bucket_table = sensitivity.bucket_table
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    m = U.UnevenMap()
-    m.build(scenes.make_hill_cloud())
+    scene = sys.argv[3] if len(sys.argv) > 3 else "hill"
+    global PARAM_SETS
+    if scene == "hill":
+        m = U.UnevenMap()
+        m.build(scenes.make_hill_cloud())
+    else:
+        PARAM_SETS = PARAM_SETS[:1]
+        m = U.UnevenMap(dict(max_rho=0.08) if scene == "vocano" else None)        # run_vocano.yaml differs in max_rho only
+        m.build(np.load(os.path.join(os.getcwd(), "tests", "golden", "%s_xyz.npz" % scene))["xyz"])
     nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
     probs = scenes.random_problems(N, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
     og = O.OracleGrid()

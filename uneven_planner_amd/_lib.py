@@ -26,7 +26,7 @@ class OptParams(C.Structure):
 
 class ManagerParams(C.Structure):
     _fields_ = [("piece_len", C.c_double), ("mean_vel", C.c_double), ("init_time_times", C.c_double), ("yaw_piece_times", C.c_double),
-                ("init_sig_vel", C.c_double)]
+                ("init_sig_vel", C.c_double), ("test_mode", C.c_int32), ("test_max_vel", C.c_double)]
 
 
 class FbmParams(C.Structure):

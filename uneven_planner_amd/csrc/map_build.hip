@@ -539,6 +539,7 @@ static int createMap(const uph_map_params* mp, int device, uph_map** out, bool f
     if (tx0 < 0 || tx1 > g.nx || tx0 >= tx1) { delete m; setError("uph_map_create_tile: bad x-range"); return UPH_ERR_INVALID; }
     g.x_off = tx0; g.nx_hold = tx1 - tx0;
     m->ncell = (size_t)g.nx_hold * g.ny * g.nyaw;
+    if (m->ncell >= ((size_t)1 << 31)) { setError("uph_map_create: more than 2^31 cells held by one device (the lookups index cells with 32 bits): use tiles"); delete m; return UPH_ERR_LIMIT; }
     g.cells = nullptr; g.cells32 = nullptr;
     int r = UPH_OK;
     auto alloc = [&](void** p, size_t bytes) { if (r == UPH_OK && hipMalloc(p, bytes) != hipSuccess) { setError("uph_map_create: hipMalloc of the grid failed"); r = UPH_ERR_HIP; } };

@@ -11,7 +11,7 @@ namespace uph {
 template <class R>
 struct CornersT {
     R dx, dy, dyaw;            // fractional offsets diff[0..2]
-    int64_t a[2][2];           // address of (x,y) corner at yaw index w0
+    uint32_t a[2][2];          // cell index of the (x,y) corner at yaw bin 0 (held rows; < 2^31, checked when the map is created)
     int w0, w1;                // the two yaw bins
     bool inmap;
 };
@@ -24,6 +24,8 @@ UPH_HD bool isInMap(const GridDev& g, R x, R y, R yaw) {     // uneven_map.h:437
     if (x > g.hi[0] || y > g.hi[1] || yaw > g.hi[2]) return false;
     return true;
 }
+
+UPH_HD int clampIdx(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }      // boundIndex for x / y (uneven_map.h:398-409); one v_med3_i32 on the device
 
 template <class R>
 UPH_HD void locate(const GridDev& g, R x, R y, R yaw, CornersT<R>& c) {
@@ -41,41 +43,39 @@ UPH_HD void locate(const GridDev& g, R x, R y, R yaw, CornersT<R>& c) {
     c.dx = (x - cx) * g.xy_inv;
     c.dy = (y - cy) * g.xy_inv;
     // reference: atan2(sin(d), cos(d)) * yaw_inv  (:284).  d lies within one wrap of a yaw cell, so the exact range
-    // reduction d - 2*pi*rint(d/(2*pi)) gives the same angle to ~1e-17 without three transcendentals.
-    const double TWO_PI = 6.28318530717958647692;
+    // reduction d - 2*pi*rint(d/(2*pi)) gives the same angle to ~1e-17 without three transcendentals.  The quotient only feeds rint():
+    // d times the rounded reciprocal picks the same integer (|d| stays below one cell + one wrap, nowhere near a half-integer quotient)
+    // and spares the twelve-instruction IEEE division sequence per sample.
+    const double TWO_PI = 6.28318530717958647692, INV_TWO_PI = 0.15915494309189533577;
     R d = yaw - cw;
-    d = d - TWO_PI * rint(d / TWO_PI);
+    d = d - TWO_PI * rint(d * INV_TWO_PI);
     c.dyaw = d * g.yaw_inv;
     // boundIndex :398-409: clamp x,y; wrap yaw modulo nyaw
-    int x0 = ix < 0 ? 0 : (ix > g.nx - 1 ? g.nx - 1 : ix);
-    int x1 = ix + 1 < 0 ? 0 : (ix + 1 > g.nx - 1 ? g.nx - 1 : ix + 1);
-    int y0 = iy < 0 ? 0 : (iy > g.ny - 1 ? g.ny - 1 : iy);
-    int y1 = iy + 1 < 0 ? 0 : (iy + 1 > g.ny - 1 ? g.ny - 1 : iy + 1);
+    const int x0 = clampIdx(ix, g.nx - 1), x1 = clampIdx(ix + 1, g.nx - 1);
+    const int y0 = clampIdx(iy, g.ny - 1), y1 = clampIdx(iy + 1, g.ny - 1);
+    // yaw passed isInMap and wm lies in [-pi, pi], so iw lies in [-1, nyaw]: ONE conditional wrap each way is boundIndex's modulo for
+    // iw and iw + 1 alike
     int w0 = iw, w1 = iw + 1;
-    // yaw passed isInMap, so iw lies in [-1, nyaw]: two conditional wraps each way cover boundIndex's modulo with margin
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        w0 = w0 > g.nyaw - 1 ? w0 - g.nyaw : (w0 < 0 ? w0 + g.nyaw : w0);
-        w1 = w1 > g.nyaw - 1 ? w1 - g.nyaw : (w1 < 0 ? w1 + g.nyaw : w1);
-    }
+    w0 = w0 > g.nyaw - 1 ? w0 - g.nyaw : (w0 < 0 ? w0 + g.nyaw : w0);
+    w1 = w1 > g.nyaw - 1 ? w1 - g.nyaw : (w1 < 0 ? w1 + g.nyaw : w1);
     c.w0 = w0; c.w1 = w1;
     // rows relative to the held part of the grid (a tile holds the x-rows [x_off, x_off + nx_hold) of the global grid: same index
     // arithmetic as the whole grid, so a lookup inside the tile is bit-identical).  Rows outside are clamped to the tile -- memory
     // safe; the host keeps trajectories inside their tile (uph_batch_upload / download checks).
-    int xa = x0 - g.x_off, xb = x1 - g.x_off;
-    xa = xa < 0 ? 0 : (xa > g.nx_hold - 1 ? g.nx_hold - 1 : xa);
-    xb = xb < 0 ? 0 : (xb > g.nx_hold - 1 ? g.nx_hold - 1 : xb);
-    c.a[0][0] = ((int64_t)xa * g.ny + y0) * g.nyaw;
-    c.a[0][1] = ((int64_t)xa * g.ny + y1) * g.nyaw;
-    c.a[1][0] = ((int64_t)xb * g.ny + y0) * g.nyaw;
-    c.a[1][1] = ((int64_t)xb * g.ny + y1) * g.nyaw;
+    const int xa = clampIdx(x0 - g.x_off, g.nx_hold - 1), xb = clampIdx(x1 - g.x_off, g.nx_hold - 1);
+    // 32-bit cell indices (the held cells number < 2^31): the 64-bit arithmetic happens once per load, as the byte offset
+    const uint32_t ra = (uint32_t)xa * (uint32_t)g.ny, rb = (uint32_t)xb * (uint32_t)g.ny, nw = (uint32_t)g.nyaw;
+    c.a[0][0] = (ra + (uint32_t)y0) * nw;
+    c.a[0][1] = (ra + (uint32_t)y1) * nw;
+    c.a[1][0] = (rb + (uint32_t)y0) * nw;
+    c.a[1][1] = (rb + (uint32_t)y1) * nw;
 }
 
 // One cell of the grid: {z, sigma, zb.x, zb.y} in the reference's RXS2 order (uneven_map.h:36-64, 427-435), stored either as four
 // doubles (32 bytes, two 16-byte loads; bit-faithful to the reference's map_buffer) or -- GridDev::cells32, BASELINE.json configs[4] --
 // as four floats (16 bytes, one load) widened to double on load: the arithmetic is fp64 either way.
 template <bool F32, class R>
-UPH_HD void loadCell(const GridDev& g, int64_t idx, R f[4]) {           // f = {sigma, zb.x, zb.y, z}
+UPH_HD void loadCell(const GridDev& g, uint32_t idx, R f[4]) {           // f = {sigma, zb.x, zb.y, z}
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef double dbl2_t __attribute__((ext_vector_type(2)));
     typedef float flt4_t __attribute__((ext_vector_type(4)));
@@ -91,7 +91,7 @@ UPH_HD void loadCell(const GridDev& g, int64_t idx, R f[4]) {           // f = {
         const flt4_t v = ((cellp32)g.cells32)[idx];
         f[3] = toReal<R>(v.x); f[0] = toReal<R>(v.y); f[1] = toReal<R>(v.z); f[2] = toReal<R>(v.w);
     } else {
-        const cellp p = (cellp)(g.cells + 4 * idx);
+        const cellp p = (cellp)(g.cells + 4 * (size_t)idx);
         const dbl2_t lo = p[0], hi = p[1];                  // (z, sigma), (zb.x, zb.y)
         f[3] = lo.x; f[0] = lo.y; f[1] = hi.x; f[2] = hi.y;
     }
@@ -113,7 +113,7 @@ UPH_HD void interpCells(const GridDev& g, const CornersT<R>& c, R val[4], R grd[
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++) loadCell<F32, R>(g, c.a[a][b] + wi, f[a][b]);
+            for (int b = 0; b < 2; b++) loadCell<F32, R>(g, c.a[a][b] + (uint32_t)wi, f[a][b]);
 #pragma unroll
         for (int k = 0; k < NF; k++) {
             const R vy0 = f[0][0][k] * (1 - dx) + f[1][0][k] * dx;       // v00 / v01 of uneven_map.h:297-300

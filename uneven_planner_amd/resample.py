@@ -13,7 +13,7 @@ import math
 import numpy as np
 
 # plan_manager/params/run_hill.yaml:57-62
-MANAGER_PARAMS = dict(piece_len=0.3, mean_vel=0.5, init_time_times=1.2, yaw_piece_times=2.0, init_sig_vel=0.05)
+MANAGER_PARAMS = dict(piece_len=0.3, mean_vel=0.5, init_time_times=1.2, yaw_piece_times=2.0, init_sig_vel=0.05, test_mode=0, test_max_vel=0.5)
 
 
 def hermite_path(start, goal, interval=0.06):
@@ -53,9 +53,13 @@ def hermite_path(start, goal, interval=0.06):
 
 
 def resample_path(init_path, piece_len=0.3, mean_vel=0.5, init_time_times=1.2, yaw_piece_times=2.0,
-                  init_sig_vel=0.05):
+                  init_sig_vel=0.05, test_mode=False, test_max_vel=0.5):
     """plan_manager.cpp:62-132.  init_path: (M,3) [x,y,yaw].  Returns the optimizeSE2Traj argument dict:
-    init_xy, end_xy (2x3: P,V,A columns), inner_xy (2 x (Nxy-1)), init_yaw, end_yaw (3), inner_yaw (Nyaw-1), total_time."""
+    init_xy, end_xy (2x3: P,V,A columns), inner_xy (2 x (Nxy-1)), init_yaw, end_yaw (3), inner_yaw (Nyaw-1), total_time.
+    test_mode: the back-end test node's variant instead, back_end/src/alm_traj_opt.cpp:73-144 (literals 0.3 / 2.0 / 0.05 / 1.2, the
+    optimiser's max_vel, one node per comb and segment at most, position nodes also feed the yaw way-points)."""
+    if test_mode:
+        piece_len, yaw_piece_times, init_sig_vel = 0.3, 2.0, 0.05
     path = np.array(init_path, dtype=np.float64).copy()
     # smooth yaw  :62-78
     for i in range(path.shape[0] - 1):
@@ -83,6 +87,16 @@ def resample_path(init_path, piece_len=0.3, mean_vel=0.5, init_time_times=1.2, y
         temp_len_yaw += temp_seg
         temp_len_pos += temp_seg
         total_len += temp_seg
+        if test_mode:                                # alm_traj_opt.cpp:122-134: `if`, and temp_node.z() joins the yaw nodes
+            if temp_len_yaw > piece_len_yaw:
+                inner_yaw.append(path[k, 2] + (1.0 - (temp_len_yaw - piece_len_yaw) / temp_seg) * dv[2])
+                temp_len_yaw -= piece_len_yaw
+            if temp_len_pos > piece_len:
+                node = path[k] + (1.0 - (temp_len_pos - piece_len) / temp_seg) * dv
+                inner_xy.append(node[:2].copy())
+                inner_yaw.append(node[2])
+                temp_len_pos -= piece_len
+            continue
         while temp_len_yaw > piece_len_yaw:
             inner_yaw.append(path[k, 2] + (1.0 - (temp_len_yaw - piece_len_yaw) / temp_seg) * dv[2])
             temp_len_yaw -= piece_len_yaw
@@ -90,7 +104,7 @@ def resample_path(init_path, piece_len=0.3, mean_vel=0.5, init_time_times=1.2, y
             node = path[k] + (1.0 - (temp_len_pos - piece_len) / temp_seg) * dv
             inner_xy.append(node[:2].copy())
             temp_len_pos -= piece_len
-    total_time = total_len / mean_vel * init_time_times   # :122
+    total_time = total_len / test_max_vel * 1.2 if test_mode else total_len / mean_vel * init_time_times   # alm_traj_opt.cpp:137 / plan_manager.cpp:122
     return dict(init_xy=init_xy, end_xy=end_xy,
                 inner_xy=np.array(inner_xy, dtype=np.float64).reshape(-1, 2).T.copy(),
                 init_yaw=init_yaw, end_yaw=end_yaw, inner_yaw=np.array(inner_yaw, dtype=np.float64),
@@ -107,7 +121,7 @@ def resample_batch(paths, cap_xy=64, cap_yaw=128, **kw):
     L = _lib.load()
     mk = dict(MANAGER_PARAMS)
     mk.update(kw)
-    mp = _lib.ManagerParams(**{k: float(v) for k, v in mk.items()})
+    mp = _lib.ManagerParams(**{k: (int(bool(v)) if k == "test_mode" else float(v)) for k, v in mk.items()})
     B = len(paths)
     arrs = [np.ascontiguousarray(p, dtype=np.float64).reshape(-1, 3) for p in paths]
     off = np.zeros(B + 1, dtype=np.int64)
