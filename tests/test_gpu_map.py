@@ -141,6 +141,12 @@ def test_init_with_map_file_cache(tmp_path):
     b = U.UnevenMap(prm).init(map_file=path)                       # reads the side-car
     assert np.array_equal(b.map_buffer, built) and np.array_equal(b.occ_buffer, a.occ_buffer)
     import os
+    import time
+    # a `.map` written AFTER the side-car (regenerated by the reference, another cloud, ...) is the source of truth: the stale side-car is ignored
+    later = time.time() + 10
+    os.utime(path, (later, later))
+    s_ = U.UnevenMap(prm).init(map_file=path)
+    assert not np.array_equal(s_.map_buffer, built) and np.abs(s_.map_buffer - built).max() < 1e-5 * max(1.0, np.abs(built).max())
     os.remove(path + ".bin")
     c = U.UnevenMap(prm).init(map_file=path)                       # reads the CSV like constructMapInput
     assert np.abs(c.map_buffer - built).max() < 1e-5 * max(1.0, np.abs(built).max()) and not np.array_equal(c.map_buffer, built)

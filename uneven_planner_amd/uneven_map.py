@@ -171,10 +171,12 @@ class UnevenMap:
     def init(self, pcd_file=None, map_file=None, xyz=None):
         """UnevenMap::init (uneven_map.cpp:73-268), data part: read the cloud, then constructMapInput() (the `.map`
         text cache) if it exists, else constructMap() on the GPU and write the cache."""
-        if map_file and os.path.exists(map_file + ".bin"):
+        # the `.map` CSV is the source of truth (the reference's cache, uneven_map.cpp:270-315); the binary side-car only stands in for it while
+        # it is at least as new -- a `.map` regenerated later (by the reference, from another cloud or other ellipsoid parameters) wins
+        if map_file and os.path.exists(map_file) and os.path.exists(map_file + ".bin") and os.path.getmtime(map_file + ".bin") >= os.path.getmtime(map_file):
             self.constructMapInputBinary(map_file + ".bin")      # bit-exact side-car of the 6-digit CSV (written below)
         elif map_file and os.path.exists(map_file):
-            self.constructMapInput(map_file)
+            self.constructMapInput(map_file)           # (cells carry the CSV's six significant digits; no side-car is derived from them)
         else:
             if xyz is None:
                 xyz = read_pcd(pcd_file)
