@@ -7,18 +7,20 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIB = {}
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        so = os.path.join(_HERE, "emu", "libemu.so")
+def lib(flags=()):
+    """flags: extra -D switches (a variant of the workgroup program, e.g. a wider scatter window); each set is its own shared object"""
+    key = tuple(flags)
+    if key not in _LIB:
+        tag = "" if not key else "_" + "_".join(f.replace("-D", "").replace("=", "") for f in key)
+        so = os.path.join(_HERE, "emu", "libemu%s.so" % tag)
         src = os.path.join(_HERE, "emu", "emu_solver.cpp")
         csrc = os.path.join(_HERE, "..", "uneven_planner_amd", "csrc")
         deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared"] + list(key) + ["-o", so, src])
         L = C.CDLL(so)
         dp = C.POINTER(C.c_double)
         L.emu_create.restype = C.c_void_p
@@ -29,8 +31,8 @@ def lib():
         L.emu_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [dp] * 14 + [C.POINTER(C.c_longlong), dp]
         L.emu_minco_op.argtypes = [C.c_int, dp]
         L.emu_set_hook.argtypes = [C.c_int, C.c_int, C.c_int] + [dp] * 7
-        _LIB = L
-    return _LIB
+        _LIB[key] = L
+    return _LIB[key]
 
 
 def _dp(a):
@@ -38,8 +40,8 @@ def _dp(a):
 
 
 class Emu:
-    def __init__(self, cells, map_params_vec, opt_params_vec):
-        self.L = lib()
+    def __init__(self, cells, map_params_vec, opt_params_vec, flags=()):
+        self.L = lib(flags)
         self.cells = np.ascontiguousarray(cells, dtype=np.float64)
         self.mp = np.ascontiguousarray(map_params_vec, dtype=np.float64)
         self.op = np.ascontiguousarray(opt_params_vec, dtype=np.float64)

@@ -165,3 +165,43 @@ def test_single_piece_problems(emu, oracle, oracle_grid):
         ro = oracle.OracleALM(oracle_grid).optimize(p)
         r2 = emu.run(2, p, x0)
         assert r2["ret"] == ro["ret"] and r2["alm_iters"] == ro["alm_iters"] and np.abs(np.asarray(ro["x"]) - r2["x"]).max() < 1e-9
+
+
+def test_yaw_scatter_window_never_misses_a_sample(analytic_cells, oracle):
+    """scatterChunk sums a yaw piece's records over a candidate-slot window (exact bounds widened by two / three slots) and lets the stored
+    tag decide; the window must contain every sample of the piece whatever the piece ratio and the accumulated round-off of the time tables.
+    The same program built with a window of +-40 slots (every slot of a chunk is a candidate) must give bit-identical gradients: position /
+    yaw piece ratios 1:1, 1:2 (PlanManager), 1:3 (test node), 1:5 and ragged ones, at the initial point and at perturbed times."""
+    from uneven_planner_amd import resample, scenes
+    mp, op = oracle.map_params_vec(), oracle.params_vec()
+    tight = E.Emu(analytic_cells, mp, op)
+    wide = E.Emu(analytic_cells, mp, op, flags=("-DUPH_SC_WLO=40", "-DUPH_SC_WHI=40", "-DUPH_SC_YB=10"))
+    rng = np.random.default_rng(77)
+    probs = scenes.random_problems(24, seed0=8800, dmin=2.0, dmax=9.0)
+    extra = []
+    for p in probs[:12]:
+        path = resample.hermite_path((p["init_xy"][0, 0], p["init_xy"][1, 0], p["init_yaw"][0]), (p["end_xy"][0, 0], p["end_xy"][1, 0], p["end_yaw"][0]))
+        extra.append(resample.resample_path(path, test_mode=True))                       # three yaw pieces per position piece
+        extra.append(resample.resample_path(path, yaw_piece_times=5.0))
+        extra.append(resample.resample_path(path, yaw_piece_times=1.0))
+        q = resample.resample_path(path, yaw_piece_times=1.7)                            # ragged ratio
+        if q["inner_yaw"].shape[0] >= q["inner_xy"].shape[1]:
+            extra.append(q)
+    n_checked = 0
+    for p in probs + extra:
+        if p["inner_yaw"].shape[0] + 1 > 128 or p["inner_xy"].shape[1] + 1 > 64 or p["inner_xy"].shape[1] < 1:
+            continue
+        a = oracle.OracleALM(oracle.OracleGrid())
+        x0 = a.setup(p)
+        for k in range(3):
+            x = x0.copy()
+            if k:
+                x[0] += rng.uniform(-0.7, 0.7)                                            # other total time: other sample / boundary alignment
+                x[1:] += rng.normal(scale=0.02, size=x.size - 1)
+            lanes = (128, 64, 256)[k]                                                     # chunk size = lanes: other chunk / piece alignments
+            tight.L.emu_set_lanes(lanes); wide.L.emu_set_lanes(lanes)
+            rt, rw = tight.run(0, p, x), wide.run(0, p, x)
+            assert rt["f"] == rw["f"] and np.array_equal(rt["g"], rw["g"]), (p["inner_xy"].shape[1], p["inner_yaw"].shape[0], k)
+            n_checked += 1
+    assert n_checked > 150
+    tight.L.emu_set_lanes(256)                                                        # (the default of the scaffolding)

@@ -75,7 +75,8 @@ vals = {}
 for line in open(out + '/pmc_summary.txt'):
     k = line.split(); vals[k[0]] = float(k[1])
 B = int(json.loads(open(out + '/bench.json').read().strip().split('\n')[-1])['config']['batch_per_gpu'])
-json.dump({'batch': B, 'fetch_kib': vals.get('FETCH_SIZE', 0.0), 'write_kib': vals.get('WRITE_SIZE', 0.0), 'launches': 1,
+import os
+json.dump({'batch': B, 'tag': 'profiles/%s_pmc_summary.txt' % os.path.basename(out).replace('prof_', ''), 'fetch_kib': vals.get('FETCH_SIZE', 0.0), 'write_kib': vals.get('WRITE_SIZE', 0.0), 'launches': 1,
            'note': 'ALM/L-BFGS solve kernel (uph_solver_kernel<*,2,2>), one launch of bench.py --steps 1 --warmup 0 (default batch); rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; see <tag>_fetch_calibration.txt for counted/requested on known patterns'},
           open(out + '/pmc_traffic.json', 'w'), indent=1)
 PY

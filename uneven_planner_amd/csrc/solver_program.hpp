@@ -41,7 +41,14 @@ namespace uph {
 #define UPH_SC_XB 9
 #endif
 #ifndef UPH_SC_YB
-#define UPH_SC_YB 10
+#define UPH_SC_YB 14
+#endif
+// widening of a yaw piece's candidate-slot window beyond its exact-arithmetic bounds (slots before / after); the tag test decides membership
+#ifndef UPH_SC_WLO
+#define UPH_SC_WLO 2
+#endif
+#ifndef UPH_SC_WHI
+#define UPH_SC_WHI 3
 #endif
 
 // SR = real type of the sample-phase arithmetic: double (the reference's, default) or f32r (fp32 sample mode, uph_common.hpp)
@@ -593,7 +600,7 @@ struct Solver {
     // same allocation (wtab sits right before rec) and are discarded by the selects.
     UPH_HD void scatterChunk(int s0, int cnt) {
         const int K1 = K + 1;
-        const float xr = (float)Nxy / (float)Nyaw;          // xy pieces per yaw piece
+        const double xr = (double)Nxy / (double)Nyaw;       // xy pieces per yaw piece
         const int i0 = s0 / K1, i1 = (s0 + cnt - 1) / K1;
         const int nxyt = 6 * (i1 - i0 + 1);
         const int XYL = (nxyt + 63) & ~63;
@@ -637,13 +644,16 @@ struct Solver {
                 Gxy[12 * i + 2 * k1 + dd] += a1;
             } else {
                 const int tt = t - XYL, mi = tt / 3, kp = tt - 3 * mi, m = m0 + mi;
-                // candidate slots: sample (i, j) sits at time (i + j / K) Txy, yaw piece m covers [m, m + 1) Tyaw = [m, m + 1) (Nxy / Nyaw) Txy.
-                // The bounds are formed in float and widened by three slots each way (float error <= 1 slot, a sample whose
-                // accumulated time lands an ulp across a yaw boundary <= 1 slot); the tag test below decides membership exactly.
-                const float x0f = (float)m * xr, x1f = (float)(m + 1) * xr;
-                const int pa = (int)x0f, pb = (int)x1f;
-                int sa = pa * K1 + (int)((x0f - (float)pa) * (float)K) - 3 - s0;
-                int sb = pb * K1 + (int)((x1f - (float)pb) * (float)K) + 4 - s0;
+                // candidate slots: sample (i, j) sits at time (i + j / K) Txy, yaw piece m covers [m, m + 1) Tyaw = [m, m + 1) (Nxy / Nyaw) Txy, i.e. in
+                // exact arithmetic the slots from p_a K1 + ceil(f_a K) up to (not including) p_b K1 + ceil(f_b K), x_a = m xr = p_a + f_a.  The sample
+                // times are accumulated sums (Q2), so a sample lying ON a yaw boundary -- every other boundary coincides with a piece boundary when
+                // piece_yaw = 2 piece_xy, where the last sample of one piece and the first of the next share the time -- may fall to either side:
+                // one slot each way, plus one slot of margin (bounds in double: their own rounding is far below a slot).  The tag test below
+                // decides membership exactly; a window of real + 5 slots (8.5 + 5 for the usual two yaw pieces per position piece) is ONE batch.
+                const double xa = (double)m * xr, xb = (double)(m + 1) * xr;
+                const int pa = (int)xa, pb = (int)xb;
+                int sa = pa * K1 + (int)((xa - (double)pa) * (double)K) - UPH_SC_WLO - s0;
+                int sb = pb * K1 + (int)((xb - (double)pb) * (double)K) + UPH_SC_WHI - s0;
                 if (m == Nyaw - 1) sb = cnt;                 // the last yaw piece also takes every clamped late sample (:751)
                 if (sa < 0) sa = 0;
                 if (sb > cnt) sb = cnt;
