@@ -57,8 +57,8 @@ typedef struct uph_ctx uph_ctx;   /* optimiser context bound to one map, one dev
 #define UPH_RET_LEFT_TILE 5    /* tile maps only: the solved path reached the border of the rows the tile holds (lookups were clamped there) */
 #define UPH_TILE_MARGIN 2.0    /* [m] a problem is accepted by a tile map when its initial path keeps this distance from the tile's border */
 
-#define UPH_MAX_PIECE_XY 64    /* Nxy  <= 64  (19 m at piece_len 0.3)  */
-#define UPH_MAX_PIECE_YAW 128  /* Nyaw <= 128                          */
+#define UPH_MAX_PIECE_XY 128   /* Nxy  <= 128 (38 m at piece_len 0.3)  */
+#define UPH_MAX_PIECE_YAW 256  /* Nyaw <= 256                          */
 #define UPH_MAX_MEM 256        /* L-BFGS history length                */
 #define UPH_MAX_PAST 8
 

@@ -189,7 +189,7 @@ def test_yaw_scatter_window_never_misses_a_sample(analytic_cells, oracle):
             extra.append(q)
     n_checked = 0
     for p in probs + extra:
-        if p["inner_yaw"].shape[0] + 1 > 128 or p["inner_xy"].shape[1] + 1 > 64 or p["inner_xy"].shape[1] < 1:
+        if p["inner_yaw"].shape[0] + 1 > 256 or p["inner_xy"].shape[1] + 1 > 128 or p["inner_xy"].shape[1] < 1:
             continue
         a = oracle.OracleALM(oracle.OracleGrid())
         x0 = a.setup(p)

@@ -104,7 +104,8 @@ def _build(tmp_path, name, text):
 def test_cpp_batch_plan_matches_ctypes_bit_for_bit(tmp_path, analytic_cells):
     """ALMTrajOpt::optimizeSE2TrajBatch (front-end paths -> uph_resample_batch -> uph_optimize_batch -> trajectories) from C++ against
     resample_batch + optimize_batch through ctypes; one path is a single piece (goal closer than a piece length), one has more pieces than the
-    compiled limit and must come back UNSUPPORTED without disturbing the others"""
+    compiled limit and one more way-points than the adapter's resampling buffers hold (2 x the limit: the resampler reports UPH_ERR_LIMIT) -- both
+    must come back UNSUPPORTED without disturbing the others"""
     import uneven_planner_amd as U
     from uneven_planner_amd import resample
     rng = np.random.default_rng(21)
@@ -115,7 +116,9 @@ def test_cpp_batch_plan_matches_ctypes_bit_for_bit(tmp_path, analytic_cells):
         paths.append(resample.hermite_path(s, g))
     paths.insert(2, resample.hermite_path((0.0, 0.0, 0.0), (0.2, 0.0, 0.0)))          # shorter than one piece: a single quintic, solved like the others
     tl = np.linspace(-4.5, 4.5, 1200)
-    paths.insert(3, np.column_stack([tl, 4.0 * np.sin(1.5 * tl), np.arctan(6.0 * np.cos(1.5 * tl))]))      # > UPH_MAX_PIECE_XY pieces
+    paths.insert(3, np.column_stack([tl, 4.0 * np.sin(3.0 * tl), np.arctan(12.0 * np.cos(3.0 * tl))]))     # ~70 m: > UPH_MAX_PIECE_XY pieces
+    tl2 = np.linspace(-4.5, 4.5, 4000)
+    paths.insert(5, np.column_stack([tl2, 4.0 * np.sin(7.0 * tl2), np.arctan(28.0 * np.cos(7.0 * tl2))]))   # ~160 m: > 2 x UPH_MAX_PIECE_XY way-points
     exe = _build(tmp_path, "batch_consumer", CONSUMER + MAIN_BATCH)
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     cells = np.ascontiguousarray(analytic_cells, dtype=np.float64)
@@ -130,14 +133,15 @@ def test_cpp_batch_plan_matches_ctypes_bit_for_bit(tmp_path, analytic_cells):
     m = U.UnevenMap()
     m.set_cells(analytic_cells)
     opt = U.ALMTrajOpt(m)
-    probs = resample.resample_batch(paths, cap_xy=128, cap_yaw=256)
+    probs = resample.resample_batch(paths, cap_xy=2048, cap_yaw=4096)
+    assert 128 < probs[3]["inner_xy"].shape[1] + 1 <= 256 and probs[5]["inner_xy"].shape[1] > 256
     out = opt.optimize_batch(probs)
     o = 0
     for b, pr in enumerate(probs):
         ret, jc, tt, npos, nang = raw[o:o + 5]; o += 5
         npos, nang = int(npos), int(nang)
         assert int(ret) == out[b]["ret"] and tt == pr["total_time"]
-        if b == 3:
+        if b in (3, 5):
             assert int(ret) == 4 and npos == 0 and nang == 0                     # UPH_RET_UNSUPPORTED
             continue
         msg = opt.getTraj(b).to_msg()

@@ -40,18 +40,32 @@ def test_smallest_problem_matches_oracle(devmap, oracle, oracle_grid):
     assert out["ret"] in (0, 2) and np.isfinite(out["x"]).all()
 
 
-def test_largest_supported_problem(devmap, oracle, oracle_grid):
-    """Nxy = 64 / Nyaw = 128 (UPH_MAX_PIECE_*): 19 m path, one evaluation against the oracle"""
+def _winding_path(k, amp):
+    """a sinusoid across the 10 m map sampled every ~0.06 m like a front-end path; yaw = unwrapped tangent"""
+    x = np.linspace(-4.6, 4.6, 4001)
+    y = -0.5 + amp * np.sin(k * x)
+    arc = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(x), np.diff(y)))])
+    sq = np.linspace(0.0, arc[-1], int(arc[-1] / 0.06) + 1)
+    xs, ys = np.interp(sq, arc, x), np.interp(sq, arc, y)
+    yaw = np.unwrap(np.arctan2(np.gradient(ys), np.gradient(xs)))
+    return np.column_stack([xs, ys, yaw]), arc[-1]
+
+
+@pytest.mark.parametrize("target", [64, 128])
+def test_largest_supported_problem(devmap, oracle, oracle_grid, target):
+    """paths at the old and the new compiled limit -- about 19 m (Nxy <= 64, Nyaw <= 128: four registers per lane in the two-loop) and about
+    38 m (Nxy <= 128 = UPH_MAX_PIECE_XY, Nyaw <= 256, n up to 511: eight registers per lane, two-row prefetch ring): one evaluation against
+    the oracle, then a capped solve (two ALM passes of at most 40 L-BFGS iterations: history up to 39 pairs through the NQ-register two-loop)"""
     import uneven_planner_amd as U
     from uneven_planner_amd import resample
-    pts = [(-4.6 + 0.148 * i, -4.0 + 1.2 * np.sin(0.5 * i * 0.148), 0.0) for i in range(64)]
-    path = np.array(pts)
-    path[:, 2] = np.arctan2(np.gradient(path[:, 1]), np.gradient(path[:, 0]))
-    # densify to 0.06 m like the front-end output
-    dense = np.concatenate([np.linspace(path[i], path[i + 1], 4, endpoint=False) for i in range(len(path) - 1)] + [path[-1:]])
-    p = resample.resample_path(dense)
+    p = None
+    for k in np.arange(0.4, 6.0, 0.02):                       # more periods = longer path: pick the first one that lands just under the limit
+        path, length = _winding_path(k, 3.2)
+        if length > 0.3 * (target - 6):
+            p = resample.resample_path(path)
+            break
     nxy, nyaw = p["inner_xy"].shape[1] + 1, p["inner_yaw"].shape[0] + 1
-    assert 30 <= nxy <= 64 and nyaw <= 128
+    assert target - 8 <= nxy <= target and nyaw <= 2 * target, (nxy, nyaw)
     opt = U.ALMTrajOpt(devmap)
     opt.upload([p])
     f, g = opt.eval_batch(opt.x0_packed([p]))
@@ -59,6 +73,13 @@ def test_largest_supported_problem(devmap, oracle, oracle_grid):
     x0 = a.setup(p)
     fo, go, _ = a.eval(x0)
     assert abs(f[0] - fo) / abs(fo) < 1e-9 and rel(go, g[0]) < 1e-8
+    prm = dict(inner_max_iter=40.0, max_iter=1.0)
+    o2 = U.ALMTrajOpt(devmap, params=prm)
+    o2.set_rho(1.0)
+    out = o2.optimize_batch([p])[0]
+    ro = oracle.OracleALM(oracle_grid, prm).optimize(p)
+    assert out["ret"] == ro["ret"] and out["lbfgs_iters"] == ro["lbfgs_iters"] and out["evals"] == ro["evals"]
+    assert abs(out["cost"] - ro["cost"]) <= 1e-5 * abs(ro["cost"]) and rel(ro["x"], out["x"]) < 1e-5, (nxy, rel(ro["x"], out["x"]))
 
 
 def test_limits_and_argument_errors(devmap):
@@ -67,8 +88,8 @@ def test_limits_and_argument_errors(devmap):
     opt = U.ALMTrajOpt(devmap)
     p = scenes.random_problems(1, seed0=2000, dmin=3.0, dmax=4.0)[0]
     big = dict(p)
-    big["inner_xy"] = np.zeros((2, 70))
-    big["inner_yaw"] = np.zeros(140)
+    big["inner_xy"] = np.zeros((2, 130))                     # 131 position pieces > UPH_MAX_PIECE_XY = 128
+    big["inner_yaw"] = np.zeros(262)
     with pytest.raises(U._lib.UnevenHipError):
         opt.upload([big])                                       # UPH_ERR_LIMIT
     bad = dict(p)
@@ -181,8 +202,8 @@ def test_unsupported_problem_does_not_fail_its_neighbours(analytic_cells):
     good = scenes.random_problems(3, seed0=2100, dmin=3.0, dmax=5.0)
     fewer_yaw = dict(good[0])
     fewer_yaw["inner_yaw"] = good[0]["inner_yaw"][:good[0]["inner_xy"].shape[1] - 2]
-    long_ = resample.resample_path(np.column_stack([np.linspace(-4.5, 4.5, 400), np.linspace(-4.4, 4.4, 400) ** 3 / 20.0, np.zeros(400)]), piece_len=0.12)
-    assert long_["inner_xy"].shape[1] + 1 > 64
+    long_ = resample.resample_path(np.column_stack([np.linspace(-4.5, 4.5, 400), np.linspace(-4.4, 4.4, 400) ** 3 / 20.0, np.zeros(400)]), piece_len=0.06)
+    assert long_["inner_xy"].shape[1] + 1 > 128
     opt = U.ALMTrajOpt(m)
     opt.set_rho(1.0)
     out = opt.optimize_batch([good[0], fewer_yaw, good[1], long_, good[2]])

@@ -111,7 +111,7 @@ def test_optimize_batch_multi_equals_single_context(analytic_cells):
     world = 3
     probs = scenes.random_problems(41, seed0=4100, dmin=3.0, dmax=6.0)
     long_ = dict(probs[5])
-    long_["inner_xy"] = np.zeros((2, 70)); long_["inner_yaw"] = np.zeros(140)        # 71 position pieces > UPH_MAX_PIECE_XY
+    long_["inner_xy"] = np.zeros((2, 140)); long_["inner_yaw"] = np.zeros(300)       # 141 position pieces > UPH_MAX_PIECE_XY
     probs.insert(17, long_)
     maps = []
     for g in range(world):

@@ -77,10 +77,10 @@ def test_known_answers_derived_by_hand(oracle):
 
 def test_capacity_overflow_is_reported_with_counts(oracle):
     from uneven_planner_amd import _lib
-    p = np.column_stack([np.linspace(0, 30, 600), np.zeros(600), np.zeros(600)])      # 30 m: about 100 position way-points > 64
+    p = np.column_stack([np.linspace(0, 60, 1200), np.zeros(1200), np.zeros(1200)])   # 60 m: about 200 position way-points > 128
     with pytest.raises(_lib.UnevenHipError, match="more way-points"):
         R.resample_batch([p])
-    assert same(R.resample_batch([p], cap_xy=128, cap_yaw=256)[0], oracle.resample(p))
+    assert same(R.resample_batch([p], cap_xy=256, cap_yaw=512)[0], oracle.resample(p))
     with pytest.raises(_lib.UnevenHipError):
         R.resample_batch([p[:1]])                                                      # a path needs two poses
 

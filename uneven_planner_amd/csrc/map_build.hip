@@ -870,7 +870,16 @@ Clique* getClique(const std::vector<int>& devs, const RcclApi* api, std::string&
     if (r != ncclSuccess) { why = std::string("ncclCommInitAll: ") + api->GetErrorString(r); delete q; return nullptr; }
     q->streams.assign(devs.size(), nullptr);
     for (size_t g = 0; g < devs.size(); g++) {
-        if (hipSetDevice(devs[g]) != hipSuccess || hipStreamCreateWithFlags(&q->streams[g], hipStreamNonBlocking) != hipSuccess) { why = "hipStreamCreate for the RCCL clique failed"; return nullptr; }
+        if (hipSetDevice(devs[g]) != hipSuccess || hipStreamCreateWithFlags(&q->streams[g], hipStreamNonBlocking) != hipSuccess) {
+            why = "hipStreamCreate for the RCCL clique failed";
+            for (size_t h = 0; h < devs.size(); h++) {      // give back what was made
+                hipSetDevice(devs[h]);
+                if (q->streams[h]) hipStreamDestroy(q->streams[h]);
+                if (q->comms[h]) api->CommDestroy(q->comms[h]);
+            }
+            delete q;
+            return nullptr;
+        }
     }
     g_cliques.push_back(q);
     return q;
@@ -984,7 +993,9 @@ int multiBuild(uph_map* const* maps, int n, const char* who, Fit fit) {
             int per, x0, x1;
             slabOf(nx, g, n, per, x0, x1);
             if (x1 <= x0) continue;
-            th.emplace_back([&, g, x0, x1]() { rc[g] = fit(maps[g], x0, x1); if (rc[g] != UPH_OK) err[g] = uph_last_error(); });
+            auto work = [&, g, x0, x1]() { rc[g] = fit(maps[g], x0, x1); if (rc[g] != UPH_OK) err[g] = uph_last_error(); };
+            try { th.emplace_back(work); }
+            catch (...) { work(); }       // no thread to be had: this slab is fitted here (nothing throws across the ABI)
         }
         for (auto& t : th) t.join();
     }
@@ -997,7 +1008,11 @@ int multiBuild(uph_map* const* maps, int n, const char* who, Fit fit) {
     t0 = std::chrono::steady_clock::now();
     {
         std::vector<std::thread> th;
-        for (int g = 0; g < n; g++) th.emplace_back([&, g]() { rc[g] = uph_map_commit(maps[g]); if (rc[g] != UPH_OK) err[g] = uph_last_error(); });
+        for (int g = 0; g < n; g++) {
+            auto work = [&, g]() { rc[g] = uph_map_commit(maps[g]); if (rc[g] != UPH_OK) err[g] = uph_last_error(); };
+            try { th.emplace_back(work); }
+            catch (...) { work(); }
+        }
         for (auto& t : th) t.join();
     }
     for (int g = 0; g < n; g++) if (rc[g] != UPH_OK) { setError(std::string(who) + ": commit " + std::to_string(g) + ": " + err[g]); return rc[g]; }

@@ -24,7 +24,7 @@
 using namespace uph;
 
 #ifndef UPH_THOMAS_KPL
-#define UPH_THOMAS_KPL 4        // knots per lane of the knot solve: 64 lanes x 4 cover UPH_MAX_PIECE_YAW - 1 = 127 knots, 32 x 4 the 63 of an xy chain
+#define UPH_THOMAS_KPL 4        // knots per lane of the knot solve: 64 lanes x 4 cover the UPH_MAX_PIECE_YAW - 1 = 255 knots of a yaw chain, 32 x 4 the 127 of an xy chain
 #endif
 #ifndef UPH_WPS128
 #define UPH_WPS128 2
@@ -183,8 +183,9 @@ struct DevWG {
         }
     }
     __device__ __forceinline__ double bcast(double v) const { return uni(v); }   // a value every lane read from the same LDS word
-    // L-BFGS two-loop recursion (lbfgs.hpp:687-710) by wave 0 alone: d lives in registers (n <= 256 -> NQ <= 4 per lane, NQ a
-    // compile-time constant so that short problems carry no dead loads or FMAs).  A history row holds one pair: (y.s, 1/(y.s)), then
+    // L-BFGS two-loop recursion (lbfgs.hpp:687-710) by wave 0 alone: d lives in registers (n <= 512 -> NQ <= 8 per lane, NQ a
+    // compile-time constant so that short problems carry no dead loads or FMAs; the paths of more than 19 m, NQ >= 5, run with a
+    // prefetch ring of two rows instead of five so that ring + direction stay within 80 registers).  A history row holds one pair: (y.s, 1/(y.s)), then
     // s and y, both zero-padded to NQ full registers (uph_common.hpp histRowDoubles), so a chain step streams its pair with
     // unconditional 16-byte loads off ONE scalar base -- no exec masking for ragged rows, half the load instructions, one
     // address register.  Lane l holds elements (2l, 2l+1) of every 128-element group and, for odd NQ, element 64 (NQ-1) + l.
@@ -234,7 +235,14 @@ struct DevWG {
             if (NQ == 1) return a[0] * b_[0];
             if (NQ == 2) return fma(a[1], b_[1], a[0] * b_[0]);
             if (NQ == 3) return fma(a[2], b_[2], fma(a[1], b_[1], a[0] * b_[0]));
-            return fma(a[1], b_[1], a[0] * b_[0]) + fma(a[3 % NQ], b_[3 % NQ], a[2 % NQ] * b_[2 % NQ]);
+            if (NQ == 4) return fma(a[1], b_[1], a[0] * b_[0]) + fma(a[3 % NQ], b_[3 % NQ], a[2 % NQ] * b_[2 % NQ]);
+            // NQ = 5 .. 8: two fma chains over the even / odd registers (fixed order), then their sum
+            double e = a[0] * b_[0], o = a[1 % NQ] * b_[1 % NQ];
+#pragma unroll
+            for (int q = 2; q < NQ; q += 2) e = fma(a[q], b_[q], e);
+#pragma unroll
+            for (int q = 3; q < NQ; q += 2) o = fma(a[q], b_[q], o);
+            return e + o;
         };
         // Steady-state groups of PF steps carry no conditionals: every step re-fills its ring slot unconditionally (all m ring
         // rows exist, so running a few rows past `bound` is harmless), which lets the ring live in fixed registers with exact
@@ -451,7 +459,11 @@ struct DevWG {
             if (nq == 1) twoLoopT<1, PF>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
             else if (nq == 2) twoLoopT<2, PF>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
             else if (nq == 3) twoLoopT<3, PF>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
-            else twoLoopT<4, PF>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
+            else if (nq == 4) twoLoopT<4, PF>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
+            else if (nq == 5) twoLoopT<5, 2>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
+            else if (nq == 6) twoLoopT<6, 2>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
+            else if (nq == 7) twoLoopT<7, 2>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
+            else twoLoopT<8, 2>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
@@ -1163,10 +1175,12 @@ int uph_optimize_batch_multi(uph_ctx* const* ctxs, int32_t n_gpus, int32_t B, co
     for (int g = 0; g < n_gpus; g++) {
         if (share[g].empty()) continue;
         for (int b : share[g]) { pg[g].push_back(probs[b]); rg[g].push_back(results[b]); }      // shallow: the arrays stay the caller's
-        th.emplace_back([&, g]() {
+        auto work = [&, g]() {
             rc[g] = uph_optimize_batch(ctxs[g], (int32_t)pg[g].size(), pg[g].data(), rg[g].data());
             if (rc[g] != UPH_OK) err[g] = g_last_error;      // (thread-local in the worker)
-        });
+        };
+        try { th.emplace_back(work); }
+        catch (...) { work(); }           // no thread to be had: this share runs here (nothing throws across the ABI)
     }
     for (auto& t : th) t.join();
     // a share whose problems are ALL unsupported fails like a batch of its own would; the other shares' results stand.  The call reports

@@ -26,8 +26,8 @@
 
 namespace uph {
 
-constexpr int MAX_PIECE_XY = 64;
-constexpr int MAX_PIECE_YAW = 128;
+constexpr int MAX_PIECE_XY = 128;
+constexpr int MAX_PIECE_YAW = 256;
 constexpr int MAX_MEM = 256;
 constexpr int MAX_PAST = 8;
 

@@ -111,7 +111,7 @@ def resample_path(init_path, piece_len=0.3, mean_vel=0.5, init_time_times=1.2, y
                 total_time=float(total_time))
 
 
-def resample_batch(paths, cap_xy=64, cap_yaw=128, **kw):
+def resample_batch(paths, cap_xy=128, cap_yaw=256, **kw):
     """the same stage for a batch of front-end paths through the native routine (uph_resample_batch, csrc/resample_host.cpp): list of
     (M_i,3) arrays -> list of optimizeSE2Traj argument dicts.  Needs libunevenhip.so (no GPU); raises when a path needs more than
     cap_xy / cap_yaw way-points (defaults: UPH_MAX_PIECE_XY, UPH_MAX_PIECE_YAW)."""
