@@ -355,14 +355,23 @@ struct DevWG {
     // locally -- all lanes in parallel, no neighbour involved.  The serial part then carries ONLY the lane's last knot: one DPP shift
     // and one 2x2 mat-vec per step, ceil(len / KPL) steps, instead of a shift and KPL dependent mat-vecs; the other knots follow from
     // the final hand-over in parallel.  Same recurrence, other association of the products (differences at the 1e-16 level).
-    template <bool XY, bool ADJ, int KPL>
-    __device__ __forceinline__ void thomasWave(const double* tab, double* buf, int len_) {
-        const int len = uni(len_);
+    // LAYOUT: which chains a wave carries.  0 = the yaw chain on all 64 lanes (<= 255 knots); 1 = the x and y chains on lanes 0-31 / 32-63
+    // (<= 127 knots each); 2 = all three on ONE wave -- yaw on lanes 0-31 (<= 127 knots), x on 32-47, y on 48-63 (<= 63 knots each) --, which
+    // is every trajectory of up to 64 position / 128 yaw pieces: the other wave of the workgroup then skips the solve altogether instead of
+    // executing the same ~450 instructions for a dozen active lanes (7 % of an evaluation's vector instructions).  Neighbouring chains do
+    // not see each other: a chain's first knot has M1 = 0 (nothing is taken from the lane below), and a chain never fills its lane range
+    // completely (len < lanes x KPL), so the slot after its last knot carries zero factors and nothing is taken from the lane above.
+    template <int LAYOUT, bool ADJ, int KPL>
+    __device__ __forceinline__ void thomasWave(const double* tab, double* bw, int lenW_, double* bx, int lenX_) {
         const int lane = flane();
-        const int hl = XY ? (lane & 31) : lane;
+        const bool isw = LAYOUT == 0 || (LAYOUT == 2 && lane < 32);                       // this lane works on the yaw chain
+        const int hl = LAYOUT == 0 ? lane : (LAYOUT == 1 ? (lane & 31) : (lane < 32 ? lane : (lane & 15)));
+        const int dd = LAYOUT == 1 ? (lane >> 5) : ((lane >> 4) & 1);                     // x or y (position lanes)
+        const int len = LAYOUT == 0 ? uni(lenW_) : (LAYOUT == 1 ? uni(lenX_) : (isw ? uni(lenW_) : uni(lenX_)));
         const int j0 = KPL * hl + 1;                            // the lane's first knot, 1-based
-        constexpr int ks = XY ? 4 : 2, cs = XY ? 2 : 1;         // knot / component strides of the buffer
-        double* pk = buf + (size_t)(j0 - 1) * ks + (XY ? (lane >> 5) : 0);
+        const int ks = isw ? 2 : 4, cs = isw ? 1 : 2;           // knot / component strides of the buffer
+        double* pk = isw ? bw + (size_t)(j0 - 1) * 2 : bx + (size_t)(j0 - 1) * 4 + dd;
+        const int lmax = LAYOUT == 0 ? uni(lenW_) : (LAYOUT == 1 ? uni(lenX_) : (uni(lenW_) > uni(lenX_) ? uni(lenW_) : uni(lenX_)));
         double c[KPL][2], F[KPL][4], Qm[KPL][4], M2[KPL][4];
         // ---- forward composition (ascending knots)
 #pragma unroll
@@ -386,7 +395,7 @@ struct DevWG {
                 F[k][2] = -fma(M1[3], F[k - 1][2], M1[2] * F[k - 1][0]); F[k][3] = -fma(M1[3], F[k - 1][3], M1[2] * F[k - 1][1]);
             }
         }
-        const int steps = (len + KPL - 1) / KPL;
+        const int steps = (lmax + KPL - 1) / KPL;               // (uniform: the longest chain of the wave)
         double y0 = 0.0, y1 = 0.0;
         for (int s = 0; s < steps; s++) {
             const double p0 = shr1(y0), p1 = shr1(y1);
@@ -437,12 +446,15 @@ struct DevWG {
     template <bool ADJ>
     __device__ __forceinline__ void thomasT(const double* tab, double* bw, int lenW, double* bx, int lenX) {
         __builtin_amdgcn_s_setprio(3);              // dependency chains: let them win the issue arbitration
-        if (NW >= 2) {
-            if (wave == 0) thomasWave<false, ADJ, UPH_THOMAS_KPL>(tab, bw, lenW);
-            else if (wave == 1) thomasWave<true, ADJ, UPH_THOMAS_KPL>(tab, bx, lenX);
+        const bool packed = uni(lenW) <= 32 * UPH_THOMAS_KPL - 1 && uni(lenX) <= 16 * UPH_THOMAS_KPL - 1;
+        if (packed) {
+            if (wave == 0) thomasWave<2, ADJ, UPH_THOMAS_KPL>(tab, bw, lenW, bx, lenX);
+        } else if (NW >= 2) {
+            if (wave == 0) thomasWave<0, ADJ, UPH_THOMAS_KPL>(tab, bw, lenW, bx, lenX);
+            else if (wave == 1) thomasWave<1, ADJ, UPH_THOMAS_KPL>(tab, bw, lenW, bx, lenX);
         } else {
-            thomasWave<false, ADJ, UPH_THOMAS_KPL>(tab, bw, lenW);
-            thomasWave<true, ADJ, UPH_THOMAS_KPL>(tab, bx, lenX);
+            thomasWave<0, ADJ, UPH_THOMAS_KPL>(tab, bw, lenW, bx, lenX);
+            thomasWave<1, ADJ, UPH_THOMAS_KPL>(tab, bw, lenW, bx, lenX);
         }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
