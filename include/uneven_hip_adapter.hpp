@@ -235,7 +235,10 @@ public:
     int mem_size = 256, past = 3, int_K = 16;
     bool in_opt = false;
 
+    ALMTrajOpt() = default;
     ~ALMTrajOpt() { if (ctx_) uph_ctx_destroy(ctx_); }
+    ALMTrajOpt(const ALMTrajOpt&) = delete;               // owns a device context (the reference's object is a value member that is never copied)
+    ALMTrajOpt& operator=(const ALMTrajOpt&) = delete;
 
     void setEnvironment(UnevenMapHandle* env) {          // alm_traj_opt.h:127-130
         env_ = env;
