@@ -27,6 +27,9 @@
  *   uph_map_build_multi     <- UnevenMap::constructMap (as above) sharded over the GPUs of one node from ONE host process -- the reference
  *                              is a single process (plan_manager/src/manager_node.cpp): x-slabs + one RCCL all-gather (BASELINE.json configs[3])
  *   uph_optimize_batch_multi<- B x ALMTrajOpt::optimizeSE2Traj split over per-device contexts (BASELINE.json configs[2], [4])
+ *   uph_kino_plan_batch     <- KinoAstar::plan  front_end/src/kino_astar.cpp:67-236 (one call per query; B = 1 reproduces one call), the caller of
+ *                              the map's query interface and the producer of the front-end path PlanManager resamples (plan_manager.cpp:59-60)
+ *   uph_kino_params         <- rosparam kino_astar/...  kino_astar.cpp:7-20, values of plan_manager/params/run_hill.yaml:16-30
  */
 #ifndef UNEVEN_HIP_H
 #define UNEVEN_HIP_H
@@ -39,6 +42,7 @@ extern "C" {
 
 typedef struct uph_map uph_map;   /* device-resident SE(2) -> R x S2+ terrain grid            */
 typedef struct uph_ctx uph_ctx;   /* optimiser context bound to one map, one device, one stream */
+typedef struct uph_kino uph_kino; /* front-end search context bound to one map: per-query workspaces (node pools, open heaps) in HBM */
 
 /* ---- status codes */
 #define UPH_OK 0
@@ -120,6 +124,32 @@ typedef struct uph_manager_params {
     double test_max_vel;        /* ALMTrajOpt::max_vel, run_hill.yaml:35 (0.5); read in test mode only */
 } uph_manager_params;
 
+/* ---- KinoAstar parameters: rosparam kino_astar/... (front_end/src/kino_astar.cpp:7-19), values of run_hill.yaml:16-30 */
+typedef struct uph_kino_params {
+    double yaw_resolution;      /* 3.15 : lattice yaw bin of the search (NOT the map's yaw_resolution) */
+    double lambda_heu;          /* 1.0  */
+    double weight_r2;           /* 1.0  */
+    double weight_so2;          /* 0.5  */
+    double weight_v_change;     /* 0.0  */
+    double weight_delta_change; /* 0.0  */
+    double weight_sigma;        /* 10.0 */
+    double time_interval;       /* 0.3  */
+    double collision_interval;  /* 0.06 */
+    double oneshot_range;       /* 1.0  */
+    double wheel_base;          /* 0.26 */
+    double max_steer;           /* 0.5  */
+    double max_vel;             /* 0.5  */
+} uph_kino_params;
+
+/* uph_kino_plan_batch status per query (the reference prints a message and returns an empty path for 1-4, kino_astar.cpp:86-95, 212-216, 233) */
+#define UPH_KINO_OK 0
+#define UPH_KINO_START_OCCUPIED 1
+#define UPH_KINO_GOAL_OCCUPIED 2
+#define UPH_KINO_NO_PATH 3
+#define UPH_KINO_POOL_EXHAUSTED 4
+#define UPH_KINO_EXPANSION_CAP 5   /* test hook: stopped by max_expand */
+#define UPH_KINO_INTERNAL 6
+
 /* ---- one optimizeSE2Traj call.  Matrices are column-major like Eigen::MatrixXd:
  *      init_xy/end_xy = 2x3 {P,V,A columns} -> [Px,Py,Vx,Vy,Ax,Ay]; inner_xy = 2 x n_inner_xy -> [x0,y0,x1,y1,...] */
 typedef struct uph_problem {
@@ -196,7 +226,7 @@ int uph_map_dims(const uph_map* m, int32_t dims3[3]);                       /* v
 int uph_map_set_cells(uph_map* m, const double* rxs2);
 /* any pointer may be NULL.  rxs2: ncell x 4, c: ncell, occ: ncell chars, occ_r2: nx*ny chars */
 int uph_map_get_cells(uph_map* m, double* rxs2, double* c, char* occ, char* occ_r2);
-/* constructMap on the x-slab [x0, x1): crop box + 1 cm voxel filter on the host, plane fits on the device.
+/* constructMap on the x-slab [x0, x1): crop box + 1 cm voxel filter, xy bucketing and plane fits all on the device (the host uploads the cloud).
  * xyz: n x 3 float32 (what pcl::PCDReader delivers).  Cells outside the slab are untouched.  Blocking. */
 int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x1);
 /* ---- several GPUs, one host process.  maps[g] = one map per device (same parameters and storage, whole-grid maps).  Device g produces the
@@ -242,6 +272,29 @@ int uph_frontend_query_ms(uph_map* m, double* kernel_ms);
 int64_t uph_map_filter_cloud(const float* xyz, int64_t n, float* out_xyz, int64_t cap);
 /* last uph_map_build timing: kernel milliseconds (HIP events) and number of cell-iterations processed */
 int uph_map_build_stats(uph_map* m, double* kernel_ms, int64_t* cell_iters, int64_t* cloud_points);
+/* stages of the last uph_map_build, milliseconds: out6 = cloud upload, crop box + voxel filter, bucketing + LDS sizing (all three on the device: the
+ * host only launches), plane-fit kernel (HIP events), commit (c, occupancy), the whole call (wall) */
+int uph_map_build_stages(uph_map* m, double* out6);
+/* test hook: the cloud the last uph_map_build fitted planes to, as the DEVICE filtered it (must equal uph_map_filter_cloud, the host form, bit for bit);
+ * at most cap points into out_xyz (NULL: count only); returns the count, < 0 on error */
+int64_t uph_map_built_cloud(uph_map* m, float* out_xyz, int64_t cap);
+
+/* ---- front end: KinoAstar::plan for a batch of queries, one wave64 per query (csrc/kino_search.hip).
+ * uph_kino_create = KinoAstar::init + setEnvironment (kino_astar.cpp:5-43, kino_astar.h:170-178): parameters, the Dubins radius wheel_base / tan(max_steer),
+ * a node pool of getXYNum() nodes per concurrent query.  slots = number of queries searched concurrently (each owns ~3.7 MB of HBM at 200 x 200 cells);
+ * 0 = eight per compute unit.  The map must stay alive and must not be rebuilt while a search runs. */
+int uph_kino_create(uph_map* m, const uph_kino_params* kp, int32_t slots, uph_kino** out);
+void uph_kino_destroy(uph_kino* k);
+int uph_kino_slots(const uph_kino* k);
+int uph_kino_primitives(const uph_kino* k);   /* motion primitives per expansion produced by the reference's loops (kino_astar.cpp:138-145): 15 */
+/* starts / goals [B][3] = (x, y, yaw): plan(start_state, end_state) per query.  paths [B][path_cap][3] receives front_end_path (the poses of the
+ * node chain, then the Dubins shot samples, kino_astar.h:273-292), n_path[B] its length (may exceed path_cap: truncated), status[B] UPH_KINO_*;
+ * iter_num / use_node_num [B] (may be NULL) the reference's counters.  max_expand > 0 stops a query after that many expansions (test hook).
+ * expanded (may be NULL with exp_cap = 0): [B][exp_cap][3] lattice index (ix, iy, iyaw) of every expanded node in order.  Blocking. */
+int uph_kino_plan_batch(uph_kino* k, int32_t B, const double* starts, const double* goals, int32_t path_cap, double* paths, int32_t* n_path, int32_t* status,
+                        int32_t* iter_num, int32_t* use_node_num, int32_t max_expand, int32_t exp_cap, int32_t* expanded);
+/* kernel milliseconds (HIP events) of the last uph_kino_plan_batch */
+int uph_kino_stats(uph_kino* k, double* kernel_ms);
 
 /* ---- optimiser */
 int uph_ctx_create(uph_map* m, const uph_opt_params* p, uph_ctx** out);
@@ -279,6 +332,10 @@ int uph_optimize_batch(uph_ctx* c, int32_t B, const uph_problem* probs, uph_resu
 int uph_optimize_batch_multi(uph_ctx* const* ctxs, int32_t n_gpus, int32_t B, const uph_problem* probs, uph_result* results);
 /* number of problems of the uploaded batch (0: none) */
 int uph_batch_count(const uph_ctx* c);
+/* after uph_optimize_batch_multi every context holds ITS SHARE of the batch (uph_batch_count problems, in share order): idx[k] = the caller's index
+ * of problem k of this context -- what maps the rows of uph_report_batch / uph_batch_cycles of a context back to the caller's problems.  Identity
+ * after uph_batch_upload / uph_optimize_batch. */
+int uph_batch_origin(const uph_ctx* c, int32_t* idx);
 /* split form (inputs resident in HBM before the timed region): upload -> solve (kernel only, blocking) -> download */
 int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs);
 int uph_batch_solve(uph_ctx* c);

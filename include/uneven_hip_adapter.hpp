@@ -339,8 +339,10 @@ public:
         in_opt = true;
         std::vector<uph_ctx*> cs(1, ctx_);
         for (ALMTrajOpt* q : peers) cs.push_back(q->ctx_);
+        last_ctxs_.clear(); last_B_ = 0;
         const int rc = uph_optimize_batch_multi(cs.data(), (int32_t)cs.size(), B, pr.data(), rs.data());
         in_opt = false;
+        if (rc == UPH_OK) { last_ctxs_ = cs; last_B_ = B; }                       // the contexts that now hold the shares of this batch (for the report)
         if (rc != UPH_OK) throw std::runtime_error(std::string("uph_optimize_batch_multi: ") + uph_last_error());
         for (int32_t b = 0; b < B; b++) {
             out.ret.push_back(rs[b].ret_code);
@@ -361,7 +363,23 @@ public:
     }
     // the same report for every trajectory of the last call: [B][7] = max vx, ax, ay, cur, att, sigma, non-holonomic error (rows of
     // UPH_RET_UNSUPPORTED problems describe a placeholder, not a path)
+    // After a call with `peers` the batch lives in shares on several devices: every context reports its share and the rows go back to the CALLER's
+    // order through uph_batch_origin.
     std::vector<double> getMaxVxAxAyCurAttSigBatch() {
+        if (last_ctxs_.size() > 1) {
+            std::vector<double> o((size_t)7 * last_B_, 0.0);
+            for (uph_ctx* c : last_ctxs_) {
+                const int n = uph_batch_count(c);
+                if (n <= 0) continue;                                                     // (a device whose share was empty or wholly unsupported)
+                std::vector<double> part((size_t)7 * n);
+                std::vector<int32_t> idx(n);
+                if (uph_report_batch(c, part.data()) != UPH_OK) throw std::runtime_error(std::string("uph_report_batch: ") + uph_last_error());
+                if (uph_batch_origin(c, idx.data()) != UPH_OK) throw std::runtime_error(std::string("uph_batch_origin: ") + uph_last_error());
+                for (int k = 0; k < n; k++)
+                    if (idx[k] >= 0 && idx[k] < last_B_) for (int q = 0; q < 7; q++) o[(size_t)7 * idx[k] + q] = part[(size_t)7 * k + q];
+            }
+            return o;
+        }
         const int B = uph_batch_count(ctx_);
         if (B <= 0) throw std::runtime_error("getMaxVxAxAyCurAttSig: no trajectory has been optimised on this object");
         std::vector<double> o((size_t)7 * B, 0.0);
@@ -395,6 +413,8 @@ private:
     uph_ctx* ctx_ = nullptr;
     uph_result last_{};
     std::vector<double> cxy_, cyaw_, x_;
+    std::vector<uph_ctx*> last_ctxs_;       // contexts holding the shares of the last optimizeSE2TrajBatch (this object's first)
+    int last_B_ = 0;
 };
 
 }  // namespace uneven_hip

@@ -16,6 +16,7 @@ using namespace uph;
 static int g_lanes = 256;
 struct HostWG {
     static constexpr int NT = 256;      // partial-sum emulation width (upper bound of the lanes)
+    static constexpr bool MFMA_SCATTER = false;     // the matrix-core xy scatter is a device path (DevWG::scatterXY17); the emulator runs the vector form
     int size() const { return g_lanes; }
     template <class F>
     void pfor(int n, F f) { for (int i = 0; i < n; i++) f(i); }

@@ -37,3 +37,9 @@ if cy[:, 12].sum() > 0:
     calls = cy[:, 12].sum()
     print('two-loop per call: loop1 %.0f loop2 %.0f tail %.0f  first-row wait %.0f  mean bound %.1f  calls/traj %.0f'
           % (cy[:, 8].sum() / calls, cy[:, 9].sum() / calls, cy[:, 10].sum() / calls, cy[:, 13].sum() / calls, cy[:, 11].sum() / calls, calls / len(cy)))
+# barrier profile (library built with -DUPH_BAR_PROF): cycles per evaluation a wave spends between reaching a workgroup barrier and leaving it
+if os.environ.get('UPH_BAR_PROF'):
+    ev = st['evals']
+    print('barrier wait, wave 0, cycles/eval: loops+reductions %.0f  two-loop %.0f  knot solve %.0f  scatter %.0f' % tuple(cy[:, 8 + q].sum() / ev for q in range(4)))
+    print('barrier wait, wave 1, cycles/eval: loops+reductions+scatter %.0f  two-loop+knot solve (chains it only waits for) %.0f' % (cy[:, 12].sum() / ev, cy[:, 13].sum() / ev))
+    print('whole solve cycles/eval %.0f' % (cy[:, 6].sum() / ev))

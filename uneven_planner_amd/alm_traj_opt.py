@@ -192,9 +192,15 @@ class ALMTrajOpt:
 
     def cycles(self):
         """(B,16) shader-clock cycles per phase of the last solve (generate, samples, scatter, adjoint, two-loop, scaling, total, ...)"""
-        out = np.zeros((self._B, 16), dtype=np.int64)
+        out = np.zeros((max(0, self.L.uph_batch_count(self.h)), 16), dtype=np.int64)      # (sized from the context, not from this wrapper's bookkeeping)
         _lib.check(self.L.uph_batch_cycles(self.h, out.ctypes.data_as(C.POINTER(C.c_longlong))), "uph_batch_cycles")
         return out
+
+    def origin(self):
+        """caller's index of every problem this context holds (identity unless the batch came through optimize_batch_multi)"""
+        idx = np.zeros(max(0, self.L.uph_batch_count(self.h)), dtype=np.int32)
+        _lib.check(self.L.uph_batch_origin(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32))), "uph_batch_origin")
+        return idx
 
     def download(self, full=True):
         """full = False pulls only x and the coefficients (what a planner reads); the per-sample arrays then stay on the device"""
@@ -257,10 +263,21 @@ class ALMTrajOpt:
         """uph_optimize_batch_multi: one batch over the contexts `opts` (one per device), results in the caller's order"""
         lead = opts[0]
         arr, keep = lead._make_problems(probs)
-        res, bufs = lead._result_array(lead._sizes, full)
+        sizes = list(lead._sizes)
+        res, bufs = lead._result_array(sizes, full)
         hs = (C.c_void_p * len(opts))(*[o.h for o in opts])
+        for o in opts:                     # whatever happens below, no wrapper keeps describing a batch its context no longer holds
+            o._B, o._sizes, o._last = 0, [], None
         _lib.check(lead.L.uph_optimize_batch_multi(hs, len(opts), len(probs), arr, res), "uph_optimize_batch_multi")
-        return ALMTrajOpt._collect(res, bufs)
+        out = ALMTrajOpt._collect(res, bufs)
+        # every context now holds its share: bring the wrappers' bookkeeping in step with the C contexts (sizes in share order)
+        for o in opts:
+            n = o.L.uph_batch_count(o.h)
+            if n <= 0:
+                continue
+            idx = o.origin()
+            o._B, o._sizes, o._last = int(n), [sizes[i] for i in idx], [out[i] for i in idx]
+        return out
 
     # ---- the reference's entry point -------------------------------------------------------------------------------
     def optimizeSE2Traj(self, initStateXY, endStateXY, innerPtsXY, initYaw, endYaw, innerPtsYaw, totalTime):
@@ -282,7 +299,7 @@ class ALMTrajOpt:
 
     def getMaxVxAxAyCurAttSig(self):
         """Batched post-solve report (alm_traj_opt.h:170-229 + getNonHolError): (B,7) max vx, ax, ay, cur, att, sigma, non-hol error."""
-        out = np.zeros((self._B, 7))
+        out = np.zeros((max(0, self.L.uph_batch_count(self.h)), 7))      # rows = this context's problems (see origin() after optimize_batch_multi)
         _lib.check(self.L.uph_report_batch(self.h, _dp(out)), "uph_report_batch")
         return out
 

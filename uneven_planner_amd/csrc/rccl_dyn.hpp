@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <mutex>
 #include <string>
 
 namespace uph {
@@ -25,10 +26,10 @@ struct RcclApi {
 // nullptr (and `why` filled) when no RCCL can be found
 inline const RcclApi* rcclApi(std::string& why) {
     static RcclApi api;
-    static bool tried = false, ok = false;
+    static bool ok = false;
     static std::string err;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;          // (several host threads may reach their first multi-GPU call together)
+    std::call_once(once, [&]() {
         const char* names[] = {"librccl.so.1", "librccl.so"};
         for (const char* nm : names) {
             if ((api.handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD)) != nullptr) { api.origin = std::string(nm) + " (already mapped)"; break; }
@@ -49,7 +50,7 @@ inline const RcclApi* rcclApi(std::string& why) {
             ok = api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd && api.GetErrorString;
             if (!ok) err = "librccl.so (" + api.origin + ") lacks an expected entry point";
         }
-    }
+    });
     if (!ok) { why = err; return nullptr; }
     return &api;
 }

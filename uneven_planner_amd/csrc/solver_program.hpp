@@ -608,74 +608,89 @@ struct Solver {
         int m0 = rtag[0] - 1, m1 = rtag[cnt - 1] + 1;
         if (m0 < 0) m0 = 0;
         if (m1 > Nyaw - 1) m1 = Nyaw - 1;
-        wg.pfor(XYL + 3 * (m1 - m0 + 1), [&](int t) {
-            if (t < XYL) {
-                if (t >= nxyt) return;
-                const int pi = t / 6, r = t - 6 * pi, dd = r & 1, kp = r >> 1;      // r = 2 kp + dd
-                const int i = i0 + pi;
-                const int ja = i * K1 - s0;                  // slot of the piece's sample j = 0 (negative when the piece began in the previous chunk)
-                const int jlo = ja < 0 ? -ja : 0, jhi = cnt - ja < K1 ? cnt - ja : K1;      // the piece's samples inside this chunk: j in [jlo, jhi)
-                const double* r0 = rec + dd * CHP + ja;      // grad_p[dd] of sample j at r0[j]; grad_v[dd] two rows on, grad_a[dd] four
-                // k = 2 kp and 2 kp + 1: beta0_k = s^k, beta1_k = k s^(k-1), beta2_k = k (k-1) s^(k-2) (alm_traj_opt.cpp:738-740) from the
-                // power table; for kp = 0 the absent powers are read at index 0 and meet zero factors
-                const int k0 = 2 * kp, k1 = k0 + 1;
-                const int pa = k0 >= 2 ? k0 - 2 : 0, pb = k0 >= 1 ? k0 - 1 : 0;
-                const double c1a = (double)k0, c2a = (double)(k0 * (k0 - 1)), c1b = (double)k1, c2b = (double)(k1 * k0);
-                double a0 = 0.0, a1 = 0.0;
-                const double* w = wtab;
+        // xy outputs: lane t owns (piece, dim, k-pair)
+        auto xyTask = [&](int t) {
+            const int pi = t / 6, r = t - 6 * pi, dd = r & 1, kp = r >> 1;      // r = 2 kp + dd
+            const int i = i0 + pi;
+            const int ja = i * K1 - s0;                  // slot of the piece's sample j = 0 (negative when the piece began in the previous chunk)
+            const int jlo = ja < 0 ? -ja : 0, jhi = cnt - ja < K1 ? cnt - ja : K1;      // the piece's samples inside this chunk: j in [jlo, jhi)
+            const double* r0 = rec + dd * CHP + ja;      // grad_p[dd] of sample j at r0[j]; grad_v[dd] two rows on, grad_a[dd] four
+            // k = 2 kp and 2 kp + 1: beta0_k = s^k, beta1_k = k s^(k-1), beta2_k = k (k-1) s^(k-2) (alm_traj_opt.cpp:738-740) from the
+            // power table; for kp = 0 the absent powers are read at index 0 and meet zero factors
+            const int k0 = 2 * kp, k1 = k0 + 1;
+            const int pa = k0 >= 2 ? k0 - 2 : 0, pb = k0 >= 1 ? k0 - 1 : 0;
+            const double c1a = (double)k0, c2a = (double)(k0 * (k0 - 1)), c1b = (double)k1, c2b = (double)(k1 * k0);
+            double a0 = 0.0, a1 = 0.0;
+            const double* w = wtab;
 #pragma unroll 1
-                for (int jb = 0; jb < K1; jb += UPH_SC_XB) {
-                    double e0[UPH_SC_XB], e1[UPH_SC_XB], e2[UPH_SC_XB], pA[UPH_SC_XB], pB[UPH_SC_XB], pC[UPH_SC_XB], pD[UPH_SC_XB];
+            for (int jb = 0; jb < K1; jb += UPH_SC_XB) {
+                double e0[UPH_SC_XB], e1[UPH_SC_XB], e2[UPH_SC_XB], pA[UPH_SC_XB], pB[UPH_SC_XB], pC[UPH_SC_XB], pD[UPH_SC_XB];
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_XB; u++) {
-                        const int j = jb + u;
-                        e0[u] = r0[j]; e1[u] = r0[2 * CHP + j]; e2[u] = r0[4 * CHP + j];
-                        pA[u] = w[6 * j + pa]; pB[u] = w[6 * j + pb]; pC[u] = w[6 * j + k0]; pD[u] = w[6 * j + k1];
-                    }
-#pragma unroll
-                    for (int u = 0; u < UPH_SC_XB; u++) {
-                        const int j = jb + u;
-                        const bool in = j >= jlo && j < jhi;
-                        a0 += in ? (pC[u] * e0[u] + (c1a * pB[u]) * e1[u] + (c2a * pA[u]) * e2[u]) : 0.0;
-                        a1 += in ? (pD[u] * e0[u] + (c1b * pC[u]) * e1[u] + (c2b * pB[u]) * e2[u]) : 0.0;
-                    }
+                for (int u = 0; u < UPH_SC_XB; u++) {
+                    const int j = jb + u;
+                    e0[u] = r0[j]; e1[u] = r0[2 * CHP + j]; e2[u] = r0[4 * CHP + j];
+                    pA[u] = w[6 * j + pa]; pB[u] = w[6 * j + pb]; pC[u] = w[6 * j + k0]; pD[u] = w[6 * j + k1];
                 }
-                Gxy[12 * i + 2 * k0 + dd] += a0;
-                Gxy[12 * i + 2 * k1 + dd] += a1;
-            } else {
-                const int tt = t - XYL, mi = tt / 3, kp = tt - 3 * mi, m = m0 + mi;
-                // candidate slots: sample (i, j) sits at time (i + j / K) Txy, yaw piece m covers [m, m + 1) Tyaw = [m, m + 1) (Nxy / Nyaw) Txy, i.e. in
-                // exact arithmetic the slots from p_a K1 + ceil(f_a K) up to (not including) p_b K1 + ceil(f_b K), x_a = m xr = p_a + f_a.  The sample
-                // times are accumulated sums (Q2), so a sample lying ON a yaw boundary -- every other boundary coincides with a piece boundary when
-                // piece_yaw = 2 piece_xy, where the last sample of one piece and the first of the next share the time -- may fall to either side:
-                // one slot each way, plus one slot of margin (bounds in double: their own rounding is far below a slot).  The tag test below
-                // decides membership exactly; a window of real + 5 slots (8.5 + 5 for the usual two yaw pieces per position piece) is ONE batch.
-                const double xa = (double)m * xr, xb = (double)(m + 1) * xr;
-                const int pa = (int)xa, pb = (int)xb;
-                int sa = pa * K1 + (int)((xa - (double)pa) * (double)K) - UPH_SC_WLO - s0;
-                int sb = pb * K1 + (int)((xb - (double)pb) * (double)K) + UPH_SC_WHI - s0;
-                if (m == Nyaw - 1) sb = cnt;                 // the last yaw piece also takes every clamped late sample (:751)
-                if (sa < 0) sa = 0;
-                if (sb > cnt) sb = cnt;
-                if (sb < sa) sb = sa;
-                const double* rv = rec + (6 + 2 * kp) * CHP + sa;
-                const int* tg = rtag + sa;
-                double a0 = 0.0, a1 = 0.0;
-                for (int len = sb - sa; len > 0; len -= UPH_SC_YB, rv += UPH_SC_YB, tg += UPH_SC_YB) {
-                    int tg_[UPH_SC_YB];
-                    double v0[UPH_SC_YB], v1[UPH_SC_YB];
 #pragma unroll
-                    for (int u = 0; u < UPH_SC_YB; u++) { tg_[u] = tg[u]; v0[u] = rv[u]; v1[u] = rv[CHP + u]; }
-#pragma unroll
-                    for (int u = 0; u < UPH_SC_YB; u++) {
-                        const bool in = (u < len) && (tg_[u] == m);
-                        a0 += in ? v0[u] : 0.0;
-                        a1 += in ? v1[u] : 0.0;
-                    }
+                for (int u = 0; u < UPH_SC_XB; u++) {
+                    const int j = jb + u;
+                    const bool in = j >= jlo && j < jhi;
+                    a0 += in ? (pC[u] * e0[u] + (c1a * pB[u]) * e1[u] + (c2a * pA[u]) * e2[u]) : 0.0;
+                    a1 += in ? (pD[u] * e0[u] + (c1b * pC[u]) * e1[u] + (c2b * pB[u]) * e2[u]) : 0.0;
                 }
-                Gyaw[6 * m + 2 * kp] += a0;
-                Gyaw[6 * m + 2 * kp + 1] += a1;
             }
+            Gxy[12 * i + 2 * k0 + dd] += a0;
+            Gxy[12 * i + 2 * k1 + dd] += a1;
+        };
+        // yaw outputs: lane tt owns (yaw piece, k-pair)
+        auto yawTask = [&](int tt) {
+            const int mi = tt / 3, kp = tt - 3 * mi, m = m0 + mi;
+            // candidate slots: sample (i, j) sits at time (i + j / K) Txy, yaw piece m covers [m, m + 1) Tyaw = [m, m + 1) (Nxy / Nyaw) Txy, i.e. in
+            // exact arithmetic the slots from p_a K1 + ceil(f_a K) up to (not including) p_b K1 + ceil(f_b K), x_a = m xr = p_a + f_a.  The sample
+            // times are accumulated sums (Q2), so a sample lying ON a yaw boundary -- every other boundary coincides with a piece boundary when
+            // piece_yaw = 2 piece_xy, where the last sample of one piece and the first of the next share the time -- may fall to either side:
+            // one slot each way, plus one slot of margin (bounds in double: their own rounding is far below a slot).  The tag test below
+            // decides membership exactly; a window of real + 5 slots (8.5 + 5 for the usual two yaw pieces per position piece) is ONE batch.
+            const double xa = (double)m * xr, xb = (double)(m + 1) * xr;
+            const int pa = (int)xa, pb = (int)xb;
+            int sa = pa * K1 + (int)((xa - (double)pa) * (double)K) - UPH_SC_WLO - s0;
+            int sb = pb * K1 + (int)((xb - (double)pb) * (double)K) + UPH_SC_WHI - s0;
+            if (m == Nyaw - 1) sb = cnt;                 // the last yaw piece also takes every clamped late sample (:751)
+            if (sa < 0) sa = 0;
+            if (sb > cnt) sb = cnt;
+            if (sb < sa) sb = sa;
+            const double* rv = rec + (6 + 2 * kp) * CHP + sa;
+            const int* tg = rtag + sa;
+            double a0 = 0.0, a1 = 0.0;
+            for (int len = sb - sa; len > 0; len -= UPH_SC_YB, rv += UPH_SC_YB, tg += UPH_SC_YB) {
+                int tg_[UPH_SC_YB];
+                double v0[UPH_SC_YB], v1[UPH_SC_YB];
+#pragma unroll
+                for (int u = 0; u < UPH_SC_YB; u++) { tg_[u] = tg[u]; v0[u] = rv[u]; v1[u] = rv[CHP + u]; }
+#pragma unroll
+                for (int u = 0; u < UPH_SC_YB; u++) {
+                    const bool in = (u < len) && (tg_[u] == m);
+                    a0 += in ? v0[u] : 0.0;
+                    a1 += in ? v1[u] : 0.0;
+                }
+            }
+            Gyaw[6 * m + 2 * kp] += a0;
+            Gyaw[6 * m + 2 * kp + 1] += a1;
+        };
+        if constexpr (WG::MFMA_SCATTER) {
+            // The xy half is a dense contraction with a SHARED left operand: G(6 x 2P) += B(6 x 3 K1) R(3 K1 x 2P), B = the power table with the
+            // factors k, k (k-1) of alm_traj_opt.cpp:738-740, R = the records of the chunk's P pieces (samples of a piece outside the chunk
+            // masked to zero).  The device runs it on the matrix cores (DevWG::scatterXY17, v_mfma_f64_16x16x4_f64) for the reference's
+            // int_K = 16 while the other wave(s) sum the yaw blocks; any other K takes the vector path below.
+            if (K1 == 17) {
+                wg.scatterXY17(rec, wtab, Gxy, i0, i1 - i0 + 1, s0, cnt);
+                wg.pforRev(3 * (m1 - m0 + 1), yawTask);
+                return;
+            }
+        }
+        wg.pfor(XYL + 3 * (m1 - m0 + 1), [&](int t) {
+            if (t < XYL) { if (t < nxyt) xyTask(t); }
+            else yawTask(t - XYL);
         });
     }
 
@@ -1188,6 +1203,10 @@ struct Solver {
 #endif
             for (int q = 0; q < 16; q++) st.cyc[q] = cyc[q];
         });
+#ifdef UPH_BAR_PROF
+        wg.sync();
+        wg.dumpBar(&st.cyc[8]);
+#endif
     }
 
     // ------------------------------------------------------------------ optimizeSE2Traj (alm_traj_opt.cpp:168-278)

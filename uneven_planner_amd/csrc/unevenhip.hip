@@ -99,6 +99,24 @@ struct DevWG {
 #ifdef UPH_TL_PROF
     long long tl[6] = {0, 0, 0, 0, 0, 0};   // two-loop profile (tools/phase_breakdown.py): loop 1, loop 2, tail, steps, calls, first-row wait
 #endif
+#ifdef UPH_BAR_PROF
+    // barrier profile (tools/phase_breakdown.py): cycles THIS wave spent from reaching a workgroup barrier (including the drain of its own
+    // outstanding memory operations the compiler places before s_barrier) to leaving it, by the kind of region the barrier closes:
+    // 0 parallel loops / reductions, 1 two-loop (the waves that do not run the chain), 2 knot solve, 3 scatter
+    long long barw[4] = {0, 0, 0, 0};
+    __device__ __forceinline__ void bar(int cls) {
+        const long long t0 = __builtin_readcyclecounter();
+        __syncthreads();
+        barw[cls] += __builtin_readcyclecounter() - t0;
+    }
+    // wave 0 leaves its four sums at dst[0..3]; wave 1 leaves dst[4] = classes 0 + 3 (work it shares) and dst[5] = classes 1 + 2 (chains it only waits for)
+    __device__ __forceinline__ void dumpBar(long long* dst) {
+        if (lane == 0 && wave == 0) for (int q = 0; q < 4; q++) dst[q] = barw[q];
+        if (lane == 0 && wave == 1) { dst[4] = barw[0] + barw[3]; dst[5] = barw[1] + barw[2]; }
+    }
+#else
+    __device__ __forceinline__ void bar(int) { __syncthreads(); }
+#endif
     __device__ DevWG(double* scratch) : red(scratch), tid(threadIdx.x), lane(threadIdx.x & 63), wave(uni((int)(threadIdx.x >> 6))), par(0) {}
     // The lane index, re-read through an opaque barrier at the start of every parallel region: everything derived from it (LDS
     // addresses, task decompositions) is invariant across the solver's outer loops, so the compiler would otherwise hoist those
@@ -110,9 +128,66 @@ struct DevWG {
     template <class F>
     __device__ __forceinline__ void pfor(int n, F f) {
         for (int i = ftid(); i < n; i += NT) f(i);
-        __syncthreads();
+        bar(0);
     }
-    __device__ __forceinline__ void sync() { __syncthreads(); }
+    // pfor with the tasks dealt to the waves in REVERSE order (task 0 on the last wave): the companion of scatterXY17, whose tiles go to
+    // the waves in forward order
+    template <class F>
+    __device__ __forceinline__ void pforRev(int n, F f) {
+        for (int i = (NW - 1 - wave) * 64 + flane(); i < n; i += NT) f(i);
+        bar(3);
+    }
+    // ---------------------------------------------------------------------------------------------------------------------------
+    // xy half of Solver::scatterChunk on the matrix cores (alm_traj_opt.cpp:966-979 for all pieces of a sample chunk at once):
+    //     G(6 x 2P) += B(6 x 51) R(51 x 2P),    v_mfma_f64_16x16x4_f64, 13 steps of four contraction indices per tile of 16 columns
+    // contraction index q = 17 f + j (f = 0, 1, 2: grad_p, grad_v, grad_a; j = sample of the piece), column = 2 (piece of the chunk) + dim:
+    //     B[k][q] = s_j^k, k s_j^(k-1), k (k-1) s_j^(k-2)  for f = 0, 1, 2   (power table wtab[j][0..5]; rows k >= 6 of the tile are zero)
+    //     R[q][col] = record field 2 f + dim of the piece's sample j, zero when that sample is not in this chunk.
+    // Operand layout of the instruction (tools/micro/mfma_f64_probe.hip): A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, one double each;
+    // D[i][j] in lane 16 (i & 3) + j, register i >> 2.  Every out-of-range operand is SELECTED to zero (never multiplied by zero: the word read
+    // instead belongs to a neighbouring array).  Tiles go to the waves round-robin; no barrier here (the caller's yaw pass ends with one).
+    // Two accumulators alternate so that consecutive instructions do not wait for each other's result.
+#ifndef UPH_MFMA_SCATTER
+#define UPH_MFMA_SCATTER 1
+#endif
+    static constexpr bool MFMA_SCATTER = UPH_MFMA_SCATTER != 0;
+    __device__ __forceinline__ void scatterXY17(const double* rec, const double* wtab, double* Gxy, int i0_, int P_, int s0_, int cnt_) {
+        typedef double d4_t __attribute__((ext_vector_type(4)));
+        constexpr int K1 = 17, NQ = 3 * K1, CHP = NT + 1;
+        const int P = uni(P_), s0 = uni(s0_), cnt = uni(cnt_), i0 = uni(i0_);
+        const int ntile = (2 * P + 15) >> 4;
+        const int ln = flane();
+        const int c = ln & 15, kk = (ln >> 4) & 3;
+        const double c1 = (double)c, c2 = (double)(c * (c - 1));          // the row's factors k and k (k-1)
+        for (int t = wave; t < ntile; t += NW) {
+            const int col = 16 * t + c, pi = col >> 1, dd = col & 1;
+            const int pbase = (i0 + pi) * K1 - s0;                       // slot of the piece's sample j = 0 (may lie before / beyond the chunk)
+            const int jlo = pbase < 0 ? -pbase : 0;
+            int jhi = cnt - pbase < K1 ? cnt - pbase : K1;
+            if (pi >= P) jhi = 0;
+            const double* rb = rec + dd * CHP + pbase;
+            d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < (NQ + 3) / 4; st++) {
+                const int q = 4 * st + kk;
+                const int f = (q >= K1 ? 1 : 0) + (q >= 2 * K1 ? 1 : 0) + (q >= 3 * K1 ? 1 : 0);     // (f = 3: the pad q = 51, masked)
+                const int j = q - K1 * f;
+                const double wv = wtab[6 * j + c - f];
+                const double rv = rb[2 * f * CHP + j];
+                const double cf = f == 0 ? 1.0 : (f == 1 ? c1 : c2);
+                const double a = (c < 6 && c >= f && q < NQ) ? cf * wv : 0.0;
+                const double b = (j >= jlo && j < jhi && q < NQ) ? rv : 0.0;
+                if (st & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+            }
+            if (pi < P) {
+                double* gp = Gxy + 12 * (i0 + pi) + dd;
+                gp[2 * kk] += acc0[0] + acc1[0];                         // row kk
+                if (kk < 2) gp[2 * (4 + kk)] += acc0[1] + acc1[1];       // rows 4, 5
+            }
+        }
+    }
+    __device__ __forceinline__ void sync() { bar(0); }
     __device__ __forceinline__ int size() const { return NT; }
     __device__ __forceinline__ long long clock() { return (long long)__builtin_readcyclecounter(); }
     __device__ __forceinline__ long long realtime() { return (long long)__builtin_amdgcn_s_memrealtime(); }      // constant 100 MHz
@@ -135,7 +210,7 @@ struct DevWG {
 #pragma unroll
             for (int m = 0; m < M; m++) r[wave * MAXM + m] = acc[m];
         }
-        __syncthreads();
+        bar(0);
 #pragma unroll
         for (int m = 0; m < M; m++) {
             double t = r[m];
@@ -166,7 +241,7 @@ struct DevWG {
 #pragma unroll
             for (int m = 0; m < MM; m++) r[wave * MAXM + MS + m] = mx[m];
         }
-        __syncthreads();
+        bar(0);
 #pragma unroll
         for (int m = 0; m < MS; m++) {
             double t = r[m];
@@ -457,7 +532,7 @@ struct DevWG {
             thomasWave<1, ADJ, UPH_THOMAS_KPL>(tab, bw, lenW, bx, lenX);
         }
         __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
+        bar(2);
     }
     __device__ __forceinline__ void thomas(const double* tab, bool adj, double* bw, int lenW, double* bx, int lenX) {
         if (adj) thomasT<true>(tab, bw, lenW, bx, lenX);
@@ -478,7 +553,7 @@ struct DevWG {
             else twoLoopT<8, 2>(d, g, dg_out, al_lds, n, hist, m, end, bound, scale);
             __builtin_amdgcn_s_setprio(0);
         }
-        __syncthreads();
+        bar(1);
     }
     template <class F>
     __device__ __forceinline__ double maxv(int n, F f) {
@@ -488,7 +563,7 @@ struct DevWG {
         double* r = red + par * (NW * MAXM);
         par ^= 1;
         if (lane == 0) r[wave * MAXM] = a;
-        __syncthreads();
+        bar(0);
         double t = r[0];
 #pragma unroll
         for (int w = 1; w < NW; w++) t = r[w * MAXM] > t ? r[w * MAXM] : t;
@@ -599,6 +674,8 @@ struct uph_ctx {
     int n_main = 0;                         // order[0, n_main) main class, order[n_main, B) oversize class
     std::vector<int> rejected;              // per problem: 0, or the status code that made it unsupported (solved as a placeholder, reported as UPH_RET_UNSUPPORTED)
     int n_rejected = 0;
+    bool all_rejected = false;              // the last upload failed because EVERY problem was unsupported (not because of a misuse or a resource limit)
+    std::vector<int> origin;                // batch loaded by uph_optimize_batch_multi: the caller's index of each problem of this context's share (empty: identity)
     bool sample_f32 = false;                // fp32 sample arithmetic (uph_ctx_set_sample_precision)
     hipStream_t stream2 = nullptr;
     hipEvent_t evp0 = nullptr, evp1 = nullptr;      // prepare launch of an asynchronous solve
@@ -878,6 +955,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     const int K1 = c->P.int_K + 1, mem = c->P.mem_size;
     c->B = 0;                       // the context holds no batch until this upload has succeeded as a whole
+    c->origin.clear(); c->all_rejected = false;
     int first_rj = 0;
     c->desc.assign(B, TrajDesc());
     int64_t on = 0, os = 0, ocx = 0, ocy = 0, oh = 0;
@@ -920,7 +998,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         pp[b] = rj ? &placeholder : &q;
         if (rj) { if (!c->n_rejected) { why = msg; first_rj = rj; } c->n_rejected++; }
     }
-    if (c->n_rejected == B) { c->rejected.clear(); c->n_rejected = 0; setError(why); return first_rj; }
+    if (c->n_rejected == B) { c->rejected.clear(); c->n_rejected = 0; c->all_rejected = true; setError(why); return first_rj; }
     for (int b = 0; b < B; b++) {
         const uph_problem& pr = *pp[b];
         const int Nxy = pr.n_inner_xy + 1, Nyaw = pr.n_inner_yaw + 1;
@@ -994,13 +1072,15 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     HIPCHK(hipMemcpy(c->d_order.p, c->order.data(), 4 * B, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_state.p, c->state_host.data(), sizeof(TrajState) * B, hipMemcpyHostToDevice));
     // duals = 0, residuals = 0, scales = 1 (alm_traj_opt.cpp:193-203) so that the test hooks see a defined state
-    HIPCHK(hipMemset(c->d_hist.p, 0, 8 * oh));          // the pads of the history rows must be (and stay) zero
-    HIPCHK(hipMemset(c->d_dual.p, 0, 8 * 7 * os));
-    HIPCHK(hipMemset(c->d_res.p, 0, 8 * 7 * os));
-    hipLaunchKernelGGL(uph_fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_scl.as<double>(), (size_t)7 * os, 1.0);
+    // (all on the context's own stream, waited for with a STREAM synchronise: a device-wide one would block this host thread on every other
+    // context's solve in flight on the device -- and uploading batch k+1 while batch k solves is what uph_batch_solve_async is for)
+    HIPCHK(hipMemsetAsync(c->d_hist.p, 0, 8 * oh, c->stream));          // the pads of the history rows must be (and stay) zero
+    HIPCHK(hipMemsetAsync(c->d_dual.p, 0, 8 * 7 * os, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_res.p, 0, 8 * 7 * os, c->stream));
+    hipLaunchKernelGGL(uph_fill_kernel, dim3(1024), dim3(256), 0, c->stream, c->d_scl.as<double>(), (size_t)7 * os, 1.0);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
-    if (c->trace_cap > 0) HIPCHK(hipMemset(c->d_trace.p, 0, 8 * (size_t)c->trace_cap * B));
+    if (c->trace_cap > 0) HIPCHK(hipMemsetAsync(c->d_trace.p, 0, 8 * (size_t)c->trace_cap * B, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     c->trace_cap_up = c->trace_cap;
     c->B = B;
     return UPH_OK;
@@ -1059,6 +1139,12 @@ int uph_batch_solve(uph_ctx* c) {
 }
 
 int uph_batch_count(const uph_ctx* c) { return c ? c->B : UPH_ERR_INVALID; }
+// for a batch loaded by uph_optimize_batch_multi: idx[k] = the caller's index of problem k of this context's share (identity otherwise)
+int uph_batch_origin(const uph_ctx* c, int32_t* idx) {
+    if (!c || !idx || c->B <= 0) { setError("uph_batch_origin: no batch uploaded"); return UPH_ERR_INVALID; }
+    for (int b = 0; b < c->B; b++) idx[b] = c->origin.empty() ? b : c->origin[b];
+    return UPH_OK;
+}
 
 int uph_batch_stats(uph_ctx* c, double* kernel_ms, int64_t* evals, int64_t* sample_evals, int64_t* lbfgs_iters, int64_t* hist_bytes) {
     if (!c) return UPH_ERR_INVALID;
@@ -1163,8 +1249,12 @@ int uph_optimize_batch_multi(uph_ctx* const* ctxs, int32_t n_gpus, int32_t B, co
     for (int g = 0; g < n_gpus; g++) {
         if (!ctxs[g]) { setError("uph_optimize_batch_multi: null context"); return UPH_ERR_INVALID; }
         for (int h = 0; h < g; h++) if (ctxs[h] == ctxs[g]) { setError("uph_optimize_batch_multi: the same context twice"); return UPH_ERR_INVALID; }
+        if (ctxs[g]->pending) { setError("uph_optimize_batch_multi: context " + std::to_string(g) + " has an asynchronous solve in flight (uph_batch_wait first)"); return UPH_ERR_INVALID; }
     }
     if (n_gpus == 1) return uph_optimize_batch(ctxs[0], B, probs, results);
+    int dev_on_entry = -1;
+    (void)hipGetDevice(&dev_on_entry);                 // the worker threads set their own device; the caller's current device is left as it was
+    struct DevRestore { int d; ~DevRestore() { if (d >= 0) (void)hipSetDevice(d); } } dev_restore{dev_on_entry};
     std::vector<int> idx(B);
     std::iota(idx.begin(), idx.end(), 0);
     {
@@ -1185,7 +1275,7 @@ int uph_optimize_batch_multi(uph_ctx* const* ctxs, int32_t n_gpus, int32_t B, co
     std::vector<std::vector<uph_result>> rg(n_gpus);
     std::vector<std::thread> th;
     for (int g = 0; g < n_gpus; g++) {
-        if (share[g].empty()) continue;
+        if (share[g].empty()) { ctxs[g]->B = 0; ctxs[g]->origin.clear(); continue; }           // (fewer problems than contexts: this one holds no part of THIS batch, and says so)
         for (int b : share[g]) { pg[g].push_back(probs[b]); rg[g].push_back(results[b]); }      // shallow: the arrays stay the caller's
         auto work = [&, g]() {
             rc[g] = uph_optimize_batch(ctxs[g], (int32_t)pg[g].size(), pg[g].data(), rg[g].data());
@@ -1195,23 +1285,26 @@ int uph_optimize_batch_multi(uph_ctx* const* ctxs, int32_t n_gpus, int32_t B, co
         catch (...) { work(); }           // no thread to be had: this share runs here (nothing throws across the ABI)
     }
     for (auto& t : th) t.join();
-    // a share whose problems are ALL unsupported fails like a batch of its own would; the other shares' results stand.  The call reports
-    // an error only if no problem at all could be solved -- the contract of uph_optimize_batch.
-    int solved_shares = 0, first_bad = -1;
+    // A share whose problems are ALL unsupported (its upload said so: all_rejected) fails like a batch of its own would, and only that is
+    // downgraded to per-problem UPH_RET_UNSUPPORTED; the other shares' results stand.  Any other failure of a share -- a misuse, a resource
+    // limit, a HIP error -- is the call's error, reported after every successful share's results have been handed back.
+    int solved_shares = 0, first_bad = -1, hard = -1;
     for (int g = 0; g < n_gpus; g++) {
         if (share[g].empty()) continue;
         if (rc[g] == UPH_OK) {
             solved_shares++;
             for (size_t k = 0; k < share[g].size(); k++) results[share[g][k]] = rg[g][k];
-        } else if (rc[g] == UPH_ERR_INVALID || rc[g] == UPH_ERR_LIMIT) {
+            ctxs[g]->origin = share[g];
+        } else if (ctxs[g]->all_rejected) {
             if (first_bad < 0) first_bad = g;
             for (size_t k = 0; k < share[g].size(); k++) {
                 uph_result& o = results[share[g][k]];
                 o.ret_code = UPH_RET_UNSUPPORTED; o.alm_iters = o.lbfgs_iters = o.evals = 0; o.last_lbfgs_ret = rc[g];
                 o.cost = o.jerk_cost = o.piece_T_xy = o.piece_T_yaw = 0.0; o.scale_fx = 1.0; o.rho_final = ctxs[g]->rho;
             }
-        } else { setError("uph_optimize_batch_multi: device share " + std::to_string(g) + ": " + err[g]); return rc[g]; }
+        } else if (hard < 0) hard = g;
     }
+    if (hard >= 0) { setError("uph_optimize_batch_multi: device share " + std::to_string(hard) + ": " + err[hard]); return rc[hard]; }
     if (!solved_shares) { setError("uph_optimize_batch_multi: " + err[first_bad]); return rc[first_bad]; }
     return UPH_OK;
 }
