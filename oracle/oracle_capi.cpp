@@ -6,6 +6,9 @@
 #include "alm.hpp"
 #include "resample.hpp"
 #include "mapbuild.hpp"
+#include "kino_astar.hpp"
+#include <queue>
+#include <random>
 
 using namespace orc;
 
@@ -438,6 +441,103 @@ void orc_resample(const double* path, int M, const double* mp5, double* init_xy,
     for (int i = 0; i < std::min(n2[1], cap_yaw); i++) inner_yaw[i] = r.inner_yaw[i];
     *total_time = r.total_time;
     if (unwrapped) for (int i = 0; i < M; i++) unwrapped[i] = r.yaw_unwrapped[i];
+}
+
+// occupancy of a grid whose cells were set directly (uneven_map.cpp:170-179); clears first (the reference fills fresh zero buffers)
+void orc_grid_compute_occ(void* h, double min_cnormal, double max_rho) {
+    Grid* g = (Grid*)h;
+    std::fill(g->occ_buffer.begin(), g->occ_buffer.end(), 0);
+    std::fill(g->occ_r2_buffer.begin(), g->occ_r2_buffer.end(), 0);
+    MapParams p; p.min_cnormal = min_cnormal; p.max_rho = max_rho;
+    computeOccupancy(*g, p);
+}
+void orc_grid_set_occ(void* h, const char* occ, const char* occ_r2) {
+    Grid* g = (Grid*)h;
+    if (occ) std::memcpy(g->occ_buffer.data(), occ, g->occ_buffer.size());
+    if (occ_r2) std::memcpy(g->occ_r2_buffer.data(), occ_r2, g->occ_r2_buffer.size());
+}
+
+// UnevenMap::isOccupancy(pos) / isOccupancyXY(pos) (uneven_map.h:473-500): posToIndex, isInMap(idx) -> -1 outside, else the layer's value;
+// getTerrainSig (:389-396).  Any output may be null.
+void orc_grid_frontend_query(void* h, const double* pos, int n, double* sigma, int* occ, int* occ_xy) {
+    Grid* g = (Grid*)h;
+    for (int i = 0; i < n; i++) {
+        const double* p = pos + 3 * i;
+        int id[3] = {floorToInt((p[0] - g->map_origin[0]) * g->xy_resolution_inv), floorToInt((p[1] - g->map_origin[1]) * g->xy_resolution_inv),
+                     floorToInt((p[2] - g->map_origin[2]) * g->yaw_resolution_inv)};
+        const bool in = g->isInMapIdx(id);
+        if (occ) occ[i] = in ? (int)g->occ_buffer[g->toAddress(id[0], id[1], id[2])] : -1;
+        if (occ_xy) occ_xy[i] = in ? (int)g->occ_r2_buffer[(size_t)id[0] * g->voxel_num[1] + id[1]] : -1;
+        if (sigma) { RXS2 v; g->getTerrain(p, v); sigma[i] = v.sigma; }
+    }
+}
+
+// ---------------- front end: KinoAstar::plan (kino_astar.cpp:67-236) and the Dubins one-shot
+// kp[13]: yaw_resolution, lambda_heu, weight_r2, weight_so2, weight_v_change, weight_delta_change, weight_sigma, time_interval,
+//         collision_interval, oneshot_range, wheel_base, max_steer, max_vel   (rosparam order of kino_astar.cpp:7-19)
+struct OrcKino { KinoAstar ka; };
+void* orc_kino_create(void* grid, const double* kp) {
+    KinoParams p;
+    p.yaw_resolution = kp[0]; p.lambda_heu = kp[1]; p.weight_r2 = kp[2]; p.weight_so2 = kp[3]; p.weight_v_change = kp[4]; p.weight_delta_change = kp[5];
+    p.weight_sigma = kp[6]; p.time_interval = kp[7]; p.collision_interval = kp[8]; p.oneshot_range = kp[9]; p.wheel_base = kp[10]; p.max_steer = kp[11]; p.max_vel = kp[12];
+    OrcKino* k = new OrcKino();
+    k->ka.init((Grid*)grid, p);
+    return k;
+}
+void orc_kino_destroy(void* h) { delete (OrcKino*)h; }
+// stats[4] = status, iter_num, use_node_num, n_shot; path: at most path_cap poses; expanded_index: at most exp_cap (ix, iy, iyaw) triples.
+// returns the number of poses of front_end_path
+int orc_kino_plan(void* h, const double* start3, const double* end3, int max_expand, double* path, int path_cap, int* stats, int* expanded_index, int exp_cap, int* n_expanded) {
+    KinoResult r = ((OrcKino*)h)->ka.plan(start3, end3, max_expand);
+    stats[0] = r.status; stats[1] = r.iter_num; stats[2] = r.use_node_num; stats[3] = r.n_shot;
+    const int np = (int)r.path.size() / 3;
+    if (path) for (int i = 0; i < std::min(np, path_cap) * 3; i++) path[i] = r.path[i];
+    const int ne = (int)r.expanded_index.size() / 3;
+    if (n_expanded) *n_expanded = ne;
+    if (expanded_index) for (int i = 0; i < std::min(ne, exp_cap) * 3; i++) expanded_index[i] = r.expanded_index[i];
+    return np;
+}
+// out[6] = path type (0 LSL 1 RSR 2 RSL 3 LSR 4 RLR 5 LRL), t, p, q (units of rho), distance, -
+void orc_dubins(const double* from3, const double* to3, double rho, double* out) {
+    const dubins::Path p = dubins::between(from3, to3, rho);
+    out[0] = p.type; out[1] = p.len[0]; out[2] = p.len[1]; out[3] = p.len[2]; out[4] = dubins::distance(from3, to3, rho); out[5] = 0.0;
+}
+void orc_dubins_interpolate(const double* from3, const double* to3, double rho, const double* t, int n, double* out3) {
+    for (int i = 0; i < n; i++) dubins::interpolate(from3, to3, t[i], rho, out3 + 3 * i);
+}
+void orc_kino_state_transit(void* h, const double* state0, const double* ctrl2, double T, double* state1) { ((OrcKino*)h)->ka.stateTransit(state0, state1, ctrl2, T); }
+// The restated heap (KinoAstar::pushHeap / popHeap) against std::priority_queue itself on a random stream of pushes, pops and IN-PLACE
+// changes of queued keys (what kino_astar.cpp:218-229 does), NaN keys included: returns the number of pops that differed.
+int orc_heap_selfcheck(unsigned seed, int nops, int nan_every) {
+    struct Cmp { const std::vector<KinoNode>* pool; bool operator()(int a, int b) const { return (*pool)[a].f_score > (*pool)[b].f_score; } };
+    Grid g; g.init(1.0, 1.0, 0.05, 0.1);
+    KinoAstar ka; ka.init(&g, KinoParams());
+    ka.pool.assign((size_t)nops + 8, KinoNode());
+    std::priority_queue<int, std::vector<int>, Cmp> pq(Cmp{&ka.pool});
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    int next = 0, bad = 0;
+    std::vector<int> queued;
+    for (int op = 0; op < nops; op++) {
+        const double u = U(rng);
+        if (u < 0.55 || ka.heap.empty()) {
+            double f = std::floor(U(rng) * 64.0) / 8.0;                       // coarse keys: plenty of exact ties
+            if (nan_every > 0 && next % nan_every == nan_every - 1) f = std::nan("");
+            ka.pool[next].f_score = f;
+            ka.pushHeap(next); pq.push(next); queued.push_back(next);
+            next++;
+        } else if (u < 0.8) {
+            if (ka.heap[0] != pq.top()) bad++;
+            const int t = pq.top();
+            ka.popHeap(); pq.pop();
+            for (size_t i = 0; i < queued.size(); i++) if (queued[i] == t) { queued[i] = queued.back(); queued.pop_back(); break; }
+        } else if (!queued.empty()) {
+            const int t = queued[(size_t)(U(rng) * queued.size()) % queued.size()];
+            ka.pool[t].f_score -= std::floor(U(rng) * 16.0) / 8.0;          // lowered in place: no re-heapify on either side
+        }
+    }
+    while (!ka.heap.empty()) { if (ka.heap[0] != pq.top()) bad++; ka.popHeap(); pq.pop(); }
+    return bad;
 }
 
 }  // extern "C"

@@ -113,6 +113,19 @@ def lib():
         L.orc_map_write_csv.argtypes = [vp, C.c_char_p]
         L.orc_map_read_csv.restype = i
         L.orc_map_read_csv.argtypes = [vp, C.c_char_p]
+        L.orc_grid_compute_occ.argtypes = [vp, d, d]
+        L.orc_grid_set_occ.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.orc_grid_frontend_query.argtypes = [vp, dp, i, dp, ip, ip]
+        L.orc_kino_create.restype = vp
+        L.orc_kino_create.argtypes = [vp, dp]
+        L.orc_kino_destroy.argtypes = [vp]
+        L.orc_kino_plan.restype = i
+        L.orc_kino_plan.argtypes = [vp, dp, dp, i, dp, i, ip, ip, i, ip]
+        L.orc_dubins.argtypes = [dp, dp, d, dp]
+        L.orc_dubins_interpolate.argtypes = [dp, dp, d, dp, i, dp]
+        L.orc_kino_state_transit.argtypes = [vp, dp, dp, d, dp]
+        L.orc_heap_selfcheck.restype = i
+        L.orc_heap_selfcheck.argtypes = [C.c_uint, i, i]
         _LIB = L
     return _LIB
 
@@ -170,6 +183,23 @@ class OracleGrid:
         self.L.orc_grid_get_occ(self.h, occ.ctypes.data_as(C.c_char_p), occ2.ctypes.data_as(C.c_char_p))
         return occ, occ2
 
+    def compute_occ(self, min_cnormal=0.8, max_rho=0.05):
+        """occupancy of directly set cells (uneven_map.cpp:170-179)"""
+        self.L.orc_grid_compute_occ(self.h, float(min_cnormal), float(max_rho))
+
+    def set_occ(self, occ=None, occ2=None):
+        a = np.ascontiguousarray(occ, dtype=np.int8) if occ is not None else None
+        b = np.ascontiguousarray(occ2, dtype=np.int8) if occ2 is not None else None
+        self.L.orc_grid_set_occ(self.h, a.ctypes.data_as(C.c_char_p) if a is not None else None, b.ctypes.data_as(C.c_char_p) if b is not None else None)
+
+    def frontend_query(self, pos):
+        """getTerrainSig / isOccupancy / isOccupancyXY at pos (n, 3): (sigma, occ, occ_xy), -1 outside (uneven_map.h:389-396, 473-500)"""
+        pos = _f64(pos).reshape(-1, 3)
+        n = pos.shape[0]
+        sg, oc, oxy = np.zeros(n), np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        self.L.orc_grid_frontend_query(self.h, _dp(pos), n, _dp(sg), oc.ctypes.data_as(C.POINTER(C.c_int)), oxy.ctypes.data_as(C.POINTER(C.c_int)))
+        return sg, oc, oxy
+
     def all_with_grad(self, pos):
         pos = _f64(pos).reshape(-1, 3)
         n = pos.shape[0]
@@ -189,6 +219,70 @@ class OracleGrid:
         out = np.zeros((pos.shape[0], 7))
         self.L.orc_terrain_variables(self.h, _dp(pos), pos.shape[0], _dp(out))
         return out
+
+
+KINO_PARAM_ORDER = ["yaw_resolution", "lambda_heu", "weight_r2", "weight_so2", "weight_v_change", "weight_delta_change", "weight_sigma",
+                    "time_interval", "collision_interval", "oneshot_range", "wheel_base", "max_steer", "max_vel"]
+# plan_manager/params/run_hill.yaml:16-30
+HILL_KINO_PARAMS = dict(yaw_resolution=3.15, lambda_heu=1.0, weight_r2=1.0, weight_so2=0.5, weight_v_change=0.0, weight_delta_change=0.0,
+                        weight_sigma=10.0, time_interval=0.3, collision_interval=0.06, oneshot_range=1.0, wheel_base=0.26, max_steer=0.5, max_vel=0.5)
+
+
+def kino_params_vec(p=None):
+    q = dict(HILL_KINO_PARAMS)
+    if p:
+        q.update(p)
+    return np.array([float(q[k]) for k in KINO_PARAM_ORDER], dtype=np.float64)
+
+
+class OracleKinoAstar:
+    """KinoAstar::plan (front_end/src/kino_astar.cpp:67-236) through the CPU restatement oracle/kino_astar.hpp"""
+    STATUS = {0: "ok", 1: "start not free", 2: "goal not free", 3: "no path", 4: "node pool exhausted", 5: "expansion cap (checker)", 6: "key outside the table"}
+
+    def __init__(self, grid, params=None):
+        self.L = lib()
+        self.grid = grid
+        self.kp = kino_params_vec(params)
+        self.h = self.L.orc_kino_create(grid.h, _dp(self.kp))
+
+    def __del__(self):
+        try:
+            self.L.orc_kino_destroy(self.h)
+        except Exception:
+            pass
+
+    def plan(self, start, goal, max_expand=0, path_cap=4096, exp_cap=40000):
+        s, g = _f64(start), _f64(goal)
+        path = np.zeros((path_cap, 3))
+        stats = (C.c_int * 4)()
+        exp = np.zeros((exp_cap, 3), dtype=np.int32)
+        ne = C.c_int(0)
+        n = self.L.orc_kino_plan(self.h, _dp(s), _dp(g), int(max_expand), _dp(path), path_cap, stats, exp.ctypes.data_as(C.POINTER(C.c_int)), exp_cap, C.byref(ne))
+        return dict(status=stats[0], iter_num=stats[1], use_node_num=stats[2], n_shot=stats[3], path=path[:min(n, path_cap)].copy(), n_path=n,
+                    expanded=exp[:min(ne.value, exp_cap)].copy(), n_expanded=ne.value)
+
+    def state_transit(self, state0, ctrl, T):
+        out = np.zeros(3)
+        self.L.orc_kino_state_transit(self.h, _dp(_f64(state0)), _dp(_f64(ctrl)), float(T), _dp(out))
+        return out
+
+
+def dubins(frm, to, rho):
+    """OMPL DubinsStateSpace::dubins + distance: dict(type, t, p, q, distance)"""
+    out = np.zeros(6)
+    lib().orc_dubins(_dp(_f64(frm)), _dp(_f64(to)), float(rho), _dp(out))
+    return dict(type=int(out[0]), t=out[1], p=out[2], q=out[3], distance=out[4])
+
+
+def dubins_interpolate(frm, to, rho, ts):
+    ts = _f64(ts).ravel()
+    out = np.zeros((ts.size, 3))
+    lib().orc_dubins_interpolate(_dp(_f64(frm)), _dp(_f64(to)), float(rho), _dp(ts), ts.size, _dp(out))
+    return out
+
+
+def heap_selfcheck(seed=1, nops=20000, nan_every=0):
+    return lib().orc_heap_selfcheck(int(seed), int(nops), int(nan_every))
 
 
 class OracleALM:

@@ -1,0 +1,630 @@
+// libunevenhip.so -- front-end half: the kinodynamic best-first search of KinoAstar::plan for a BATCH of start / goal queries.
+//
+// Reference (paths under /root/reference/src/uneven_planner/front_end):
+//   uph_kino_plan_batch <- KinoAstar::plan  src/kino_astar.cpp:67-236 (one call per query), with
+//                          stateTransit / stateToIndex / normalizeAngle / getHeu   include/front_end/kino_astar.h:180-240
+//                          asignShotTraj (ompl::base::DubinsStateSpace::distance / interpolate, OMPL 1.4.2)   kino_astar.h:242-271
+//                          retrievePath   kino_astar.h:273-292
+//                          the map queries isInMap / isOccupancy / isOccupancyXY / getTerrainSig   uneven_map.h:389-396, 437-500
+//   uph_kino_create     <- KinoAstar::init (parameters, kino_astar.cpp:7-33) + setEnvironment (node pool = getXYNum nodes, kino_astar.h:170-178)
+//
+// One search is a strictly sequential best-first loop, so the batch axis is the parallel one: ONE wave64 per query, many waves per CU, every
+// wave with its own workspace in HBM (node pool, open heap, lattice table).  Inside a query the wave parallelises what one expansion offers:
+// the <= 64 motion primitives of a node (successor state, map test, collision samples, trilinear sigma lookup, cost) go one per lane; a heap
+// insertion fetches all ancestors of the new leaf at once and resolves the sift-up with one ballot; the Dubins shot checks its samples 64 at a
+// time.  What stays serial is what the reference's result depends on: the order in which the primitives of one expansion meet the lattice
+// table, and the sift-down of a pop.
+//
+// The open set is the reference's std::priority_queue of node pointers compared through their CURRENT f_score (kino_astar.h:49-57, 107);
+// the reference lowers an open node's f_score in place without re-heapifying (kino_astar.cpp:218-229), so the array can violate the heap
+// property and the pop order is whatever libstdc++'s __push_heap / __adjust_heap (bits/stl_heap.h) make of it.  Those two routines are
+// restated here operation for operation -- same comparisons on the same keys in the same order -- so that the expansion sequence, ties
+// included, is the reference's.  Each heap entry carries a copy of its node's f_score, kept current through a node -> heap position table
+// when the node is relaxed: the comparisons see exactly the keys the reference's pointer dereferences would.
+//
+// Platform behaviour of the reference made explicit (oracle/kino_astar.hpp header): a v = 0 primitive with steer != 0 produces the state
+// (NaN, NaN, yaw); isInMap(NaN) is true, floor(NaN) converts to INT_MIN (x86-64 cvttsd2si), getTerrainSig is NaN, and a node with key
+// (INT_MIN, INT_MIN, yaw index) and g = f = NaN enters the open set.  kFloorToInt below is that conversion; NaN keys get their own table rows.
+//
+// Arithmetic: fp64, no contraction (the reference is built without FMA: back_end / front_end CMakeLists have no -march), operation order of the
+// cited lines.  tan(steer) of the primitives and their collision sample times are formed on the host by the reference's own loops.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/uneven_hip.h"
+#include "terrain_dev.hpp"
+#include "uph_internal.hpp"
+
+using namespace uph;
+
+#pragma clang fp contract(off)
+
+#define KHIPCHK(call)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            setError(std::string(#call) + ": " + hipGetErrorString(_e));                           \
+            return UPH_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+namespace {
+
+constexpr int K_MAX_INPUTS = 64;        // motion primitives per expansion (one per lane); the reference's loops give 3 x 5 = 15
+constexpr int K_MAX_TSAMP = 8;          // collision samples per primitive (arc / collision_interval; 2 with run_hill.yaml)
+constexpr int K_CLOSE = 'a', K_OPEN = 'b';
+
+struct KinoDev {
+    double yaw_inv, lambda_heu, w_r2, w_so2, w_vch, w_dch, w_sigma, time_interval, coll_interval, oneshot_range, wheel_base, rho, tie_breaker;
+    int n_inputs, nyawk, allocate_num, nxy;
+    double in_v[K_MAX_INPUTS], in_steer[K_MAX_INPUTS], in_tan[K_MAX_INPUTS];
+    int in_nt[K_MAX_INPUTS];
+    double in_t[K_MAX_INPUTS][K_MAX_TSAMP];
+};
+
+struct __attribute__((aligned(64))) KNode {       // PathNode, kino_astar.h:34-46 (one 64-byte line)
+    double sx, sy, syaw;
+    double g, f;
+    double in_v, in_steer;
+    int parent;                                    // pool index, -1 = NULL
+    int flag;                                      // K_CLOSE / K_OPEN
+};
+struct __attribute__((aligned(16))) KHeap { double f; int id; int pad; };
+
+struct KinoWork {                                  // per-slot workspaces, slot s at base + s * stride
+    KNode* nodes;                                  // [allocate_num]
+    KHeap* heap;                                   // [allocate_num + 1]
+    int* pos;                                      // [allocate_num]  node -> heap position
+    int* key;                                      // [allocate_num]  node -> table key (for the expansion log)
+    int* table;                                    // [nxy * nyawk + nyawk]  key -> node, -1 empty; the last nyawk rows are the NaN-state keys
+    size_t table_len;
+};
+
+struct KinoIO {
+    const double* starts; const double* goals;     // [B][3]
+    double* paths; int path_cap;                   // [B][path_cap][3]
+    int* n_path; int* status; int* iter_num; int* use_node_num;      // [B]
+    int* expanded; int exp_cap;                    // [B][exp_cap][3] or null
+    int max_expand;
+};
+
+__device__ __forceinline__ int kuni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double kuni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ double klane(double v, int l) {      // l wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ int klane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+__device__ __forceinline__ int kFloorToInt(double v) {          // (int)floor(v) as x86-64 converts it
+    const double f = floor(v);
+    if (!(f >= -2147483648.0 && f <= 2147483647.0)) return INT_MIN;
+    return (int)f;
+}
+__device__ __forceinline__ double kNormalizeAngle(double angle) {      // kino_astar.h:193-204
+    double a = angle;
+    while (a > 3.14159265358979323846) a -= 6.283185307179586;
+    while (a < -3.14159265358979323846) a += 6.283185307179586;
+    return a;
+}
+// kino_astar.h:218-240 with tan(delta) handed in (formed on the host)
+__device__ __forceinline__ void kStateTransit(const KinoDev& P, double x0, double y0, double w0, double v, double delta, double tand, double T, double& x1, double& y1, double& w1) {
+    const double s = v * T;
+    const double y = s * tand / P.wheel_base;
+    if (fabs(delta) > 1e-4) {
+        const double r = s / y;
+        x1 = x0 + r * (sin(w0 + y) - sin(w0));
+        y1 = y0 - r * (cos(w0 + y) - cos(w0));
+        w1 = kNormalizeAngle(w0 + y);
+    } else {
+        x1 = x0 + s * cos(w0);
+        y1 = y0 + s * sin(w0);
+        w1 = w0;
+    }
+}
+// UnevenMap::isOccupancyXY (uneven_map.h:490-500): 1 occupied, 0 free, -1 outside
+__device__ __forceinline__ int kOccXY(const GridDev& g, const char* __restrict__ occ2, double x, double y, double w) {
+    const int ix = kFloorToInt((x - g.origin[0]) * g.xy_inv), iy = kFloorToInt((y - g.origin[1]) * g.xy_inv), iw = kFloorToInt((w - g.origin[2]) * g.yaw_inv);
+    if (ix < 0 || iy < 0 || iw < 0 || ix > g.nx - 1 || iy > g.ny - 1 || iw > g.nyaw - 1) return -1;
+    return (int)occ2[(size_t)ix * g.ny + iy];
+}
+__device__ __forceinline__ int kOcc(const GridDev& g, const char* __restrict__ occ, double x, double y, double w) {      // isOccupancy(pos), :473-488
+    const int ix = kFloorToInt((x - g.origin[0]) * g.xy_inv), iy = kFloorToInt((y - g.origin[1]) * g.xy_inv), iw = kFloorToInt((w - g.origin[2]) * g.yaw_inv);
+    if (ix < 0 || iy < 0 || iw < 0 || ix > g.nx - 1 || iy > g.ny - 1 || iw > g.nyaw - 1) return -1;
+    return (int)occ[((size_t)ix * g.ny + iy) * g.nyaw + iw];
+}
+__device__ __forceinline__ double kTerrainSig(const GridDev& g, double x, double y, double w) {      // getTerrainSig, uneven_map.h:389-396
+    if (isnan(x) || isnan(y)) return __longlong_as_double(0x7ff8000000000000ll);      // isInMap(NaN) is true, the trilinear weights are NaN
+    Corners c;
+    locate(g, x, y, w, c);
+    double tv[4];
+    terrainValues(g, c, tv);
+    return tv[0];
+}
+// lattice key of a state (stateToIndex, kino_astar.h:187-191): -1 = no table row (cannot occur for a state that passed isInMap)
+__device__ __forceinline__ int kKey(const GridDev& g, const KinoDev& P, double x, double y, double w, int idx3[3]) {
+    const int ix = kFloorToInt((x - g.origin[0]) * g.xy_inv), iy = kFloorToInt((y - g.origin[1]) * g.xy_inv);
+    const int iw = kFloorToInt((kNormalizeAngle(w) + 3.14159265358979323846) * P.yaw_inv);
+    idx3[0] = ix; idx3[1] = iy; idx3[2] = iw;
+    if (iw < 0 || iw >= P.nyawk) return -1;
+    if (ix == INT_MIN && iy == INT_MIN) return P.nxy * P.nyawk + iw;
+    if (ix < 0 || iy < 0 || ix >= g.nx || iy >= g.ny) return -1;
+    return (ix * g.ny + iy) * P.nyawk + iw;
+}
+
+// ---- Dubins (OMPL 1.4.2 DubinsStateSpace.cpp; formulas as restated in oracle/kino_astar.hpp, which cites them)
+__device__ __forceinline__ double kMod2pi(double x) {
+    const double twopi = 2.0 * 3.14159265358979323846;
+    if (x < 0 && x > -1e-7) return 0;
+    double xm = x - twopi * floor(x / twopi);
+    if (twopi - xm < .5 * 1e-6) xm = 0.;
+    return xm;
+}
+struct KDubins { int type; double len[3]; };
+__device__ void kDubinsShortest(double d, double alpha, double beta, KDubins& best) {
+    const double twopi = 2.0 * 3.14159265358979323846, ZERO = -1e-7, DMAX = 1.7976931348623157e308;
+    if (d < 1e-6 && fabs(alpha - beta) < 1e-6) { best.type = 0; best.len[0] = 0; best.len[1] = d; best.len[2] = 0; return; }
+    const double ca = cos(alpha), sa = sin(alpha), cb = cos(beta), sb = sin(beta);
+    double cand[6][3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { cand[k][0] = 0.0; cand[k][1] = DMAX; cand[k][2] = 0.0; }
+    {   // LSL
+        const double tmp = 2. + d * d - 2. * (ca * cb + sa * sb - d * (sa - sb));
+        if (tmp >= ZERO) { const double theta = atan2(cb - ca, d + sa - sb); cand[0][0] = kMod2pi(-alpha + theta); cand[0][1] = sqrt(fmax(tmp, 0.)); cand[0][2] = kMod2pi(beta - theta); }
+    }
+    {   // RSR
+        const double tmp = 2. + d * d - 2. * (ca * cb + sa * sb - d * (sb - sa));
+        if (tmp >= ZERO) { const double theta = atan2(ca - cb, d - sa + sb); cand[1][0] = kMod2pi(alpha - theta); cand[1][1] = sqrt(fmax(tmp, 0.)); cand[1][2] = kMod2pi(-beta + theta); }
+    }
+    {   // RSL
+        const double tmp = d * d - 2. + 2. * (ca * cb + sa * sb - d * (sa + sb));
+        if (tmp >= ZERO) { const double p = sqrt(fmax(tmp, 0.)); const double theta = atan2(ca + cb, d - sa - sb) - atan2(2., p); cand[2][0] = kMod2pi(alpha - theta); cand[2][1] = p; cand[2][2] = kMod2pi(beta - theta); }
+    }
+    {   // LSR
+        const double tmp = -2. + d * d + 2. * (ca * cb + sa * sb + d * (sa + sb));
+        if (tmp >= ZERO) { const double p = sqrt(fmax(tmp, 0.)); const double theta = atan2(-ca - cb, d + sa + sb) - atan2(-2., p); cand[3][0] = kMod2pi(-alpha + theta); cand[3][1] = p; cand[3][2] = kMod2pi(-beta + theta); }
+    }
+    {   // RLR
+        const double tmp = .125 * (6. - d * d + 2. * (ca * cb + sa * sb + d * (sa - sb)));
+        if (fabs(tmp) < 1.) { const double p = twopi - acos(tmp); const double theta = atan2(ca - cb, d - sa + sb); const double t = kMod2pi(alpha - theta + .5 * p); cand[4][0] = t; cand[4][1] = p; cand[4][2] = kMod2pi(alpha - beta - t + p); }
+    }
+    {   // LRL
+        const double tmp = .125 * (6. - d * d + 2. * (ca * cb + sa * sb - d * (sa - sb)));
+        if (fabs(tmp) < 1.) { const double p = twopi - acos(tmp); const double theta = atan2(-ca + cb, d + sa - sb); const double t = kMod2pi(-alpha + theta + .5 * p); cand[5][0] = t; cand[5][1] = p; cand[5][2] = kMod2pi(beta - alpha - t + p); }
+    }
+    // DubinsStateSpace.cpp dubins(): LSL first, a later word wins only if strictly shorter
+    int bt = 0;
+    double minLength = cand[0][0] + cand[0][1] + cand[0][2];
+#pragma unroll
+    for (int k = 1; k < 6; k++) { const double len = cand[k][0] + cand[k][1] + cand[k][2]; if (len < minLength) { minLength = len; bt = k; } }
+    best.type = bt;
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k == bt) { best.len[0] = cand[k][0]; best.len[1] = cand[k][1]; best.len[2] = cand[k][2]; }
+}
+__device__ void kDubinsBetween(const KinoDev& P, const double s1[3], const double s2[3], KDubins& path) {
+    const double dx = s2[0] - s1[0], dy = s2[1] - s1[1], d = sqrt(dx * dx + dy * dy) / P.rho, th = atan2(dy, dx);
+    kDubinsShortest(d, kMod2pi(s1[2] - th), kMod2pi(s2[2] - th), path);
+}
+// segment kinds of the six words: 0 left, 1 straight, 2 right
+__device__ __forceinline__ int kSegKind(int type, int i) {
+    const int tab[6][3] = {{0, 1, 0}, {2, 1, 2}, {2, 1, 0}, {0, 1, 2}, {2, 0, 2}, {0, 2, 0}};
+    int r = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) if (a == type && b == i) r = tab[a][b];
+    return r;
+}
+__device__ void kDubinsInterpolate(const KinoDev& P, const double from[3], const double to[3], const KDubins& path, double t, double out[3]) {
+    if (t >= 1.) { out[0] = to[0]; out[1] = to[1]; out[2] = to[2]; return; }
+    if (t <= 0.) { out[0] = from[0]; out[1] = from[1]; out[2] = from[2]; return; }
+    double sx = 0., sy = 0., syaw = from[2];
+    double seg = t * (path.len[0] + path.len[1] + path.len[2]);
+    for (int i = 0; i < 3 && seg > 0; ++i) {
+        const double v = fmin(seg, path.len[i]);
+        const double phi = syaw;
+        seg -= v;
+        const int kind = kSegKind(path.type, i);
+        if (kind == 0) { sx = sx + sin(phi + v) - sin(phi); sy = sy - cos(phi + v) + cos(phi); syaw = phi + v; }
+        else if (kind == 2) { sx = sx - sin(phi - v) + sin(phi); sy = sy + cos(phi - v) - cos(phi); syaw = phi - v; }
+        else { sx = sx + v * cos(phi); sy = sy + v * sin(phi); }
+    }
+    out[0] = sx * P.rho + from[0];
+    out[1] = sy * P.rho + from[1];
+    double w = fmod(syaw, 2.0 * 3.14159265358979323846);      // SO2StateSpace::enforceBounds
+    if (w < -3.14159265358979323846) w += 2.0 * 3.14159265358979323846;
+    else if (w >= 3.14159265358979323846) w -= 2.0 * 3.14159265358979323846;
+    out[2] = w;
+}
+
+// ---- open heap: libstdc++ __push_heap / __adjust_heap with comp(a, b) = a.f > b.f (NodeComparator, kino_astar.h:49-57)
+// push: the new leaf sits at position n; every ancestor is fetched at once (lane d holds the ancestor d levels up), the sift-up stops at the
+// first ancestor that is NOT greater than the value (NaN compares false: stops), the ancestors below move down one level each.
+__device__ __forceinline__ void kHeapPush(KHeap* heap, int* pos, int n, int id, double f, int lane) {
+    const int hole = n;
+    int depth = 0;                                   // number of ancestors
+    for (int h = hole; h > 0; h = (h - 1) >> 1) depth++;
+    KHeap anc; anc.f = 0.0; anc.id = -1; anc.pad = 0;
+    int apos = -1, cpos = -1;                        // position of this lane's ancestor and of the child on the path below it
+    if (lane >= 1 && lane <= depth) {
+        apos = ((hole + 1) >> lane) - 1;
+        cpos = ((hole + 1) >> (lane - 1)) - 1;
+        anc = heap[apos];
+    }
+    const unsigned long long stop = __ballot(lane >= 1 && lane <= depth && !(anc.f > f));
+    const int D = stop ? (int)__builtin_ctzll(stop) : depth + 1;      // first level that does not move
+    if (lane >= 1 && lane < D) { heap[cpos] = anc; pos[anc.id] = cpos; }
+    if (lane == 0) {
+        const int fin = ((hole + 1) >> (D - 1)) - 1;
+        KHeap e; e.f = f; e.id = id; e.pad = 0;
+        heap[fin] = e; pos[id] = fin;
+    }
+}
+// pop of the root: value = last entry, __adjust_heap(first, 0, len = n - 1, value).  The sift-down always runs to a leaf (smaller-f child,
+// the right one when neither compares greater), then the value sifts up along that path.  With E_k the entry the path met at level k
+// (k = 1..L, positions p_k) the final layout is: heap[p_{k-1}] = E_k for k <= h, heap[p_h] = value, levels below h untouched, where h walks up
+// from L while E_h.f > value.f.  Lane k keeps (E_k, p_k, p_{k-1}); one dependent load pair per level.
+__device__ __forceinline__ void kHeapPop(KHeap* heap, int* pos, int n, int lane) {
+    if (n <= 1) return;
+    const int len = n - 1;
+    KHeap value = heap[len];
+    value.f = kuni(value.f); value.id = kuni(value.id);
+    KHeap mine; mine.f = 0.0; mine.id = -1; mine.pad = 0;      // lane k: E_k
+    int my_p = -1, my_pp = -1;                                   // p_k, p_{k-1}
+    int hole = 0, second = 0, L = 0;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        const KHeap r = heap[second], l = heap[second - 1];      // (uniform addresses: one transaction each)
+        const double rf = kuni(r.f), lf = kuni(l.f);
+        const bool takeLeft = rf > lf;                           // comp(first + second, first + (second - 1))
+        if (takeLeft) second--;
+        L++;
+        if (lane == L) { mine.f = takeLeft ? lf : rf; mine.id = kuni(takeLeft ? l.id : r.id); my_p = second; my_pp = hole; }
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        const KHeap l = heap[second - 1];
+        L++;
+        if (lane == L) { mine.f = kuni(l.f); mine.id = kuni(l.id); my_p = second - 1; my_pp = hole; }
+        hole = second - 1;
+    }
+    // sift-up of value from level L: h = L; while (h > 0 && E_h.f > value.f) h--
+    const unsigned long long keep = __ballot(lane >= 1 && lane <= L && !(mine.f > value.f));      // levels that stop the walk
+    int h = 0;
+    if (keep) h = 63 - (int)__builtin_clzll(keep);               // highest such level <= L
+    // entries at levels <= h move up one level; levels > h stay where they were (they were never written)
+    if (lane >= 1 && lane <= h) { heap[my_pp] = mine; pos[mine.id] = my_pp; }
+    const int ph = h == 0 ? 0 : klane(my_p, h);
+    if (lane == 0) { heap[ph] = value; pos[value.id] = ph; }
+}
+
+// ------------------------------------------------------------------------------------------------ the search kernel: one wave64 per query
+__global__ __launch_bounds__(64) void uph_kino_kernel(GridDev g, const char* __restrict__ occ, const char* __restrict__ occ2, const KinoDev* __restrict__ Pp, KinoWork W, size_t node_stride,
+                                                      size_t heap_stride, size_t table_stride, KinoIO io, int B) {
+    const int lane = threadIdx.x;
+    const KinoDev& P = *Pp;
+    KNode* nodes = W.nodes + (size_t)blockIdx.x * node_stride;
+    KHeap* heap = W.heap + (size_t)blockIdx.x * heap_stride;
+    int* pos = W.pos + (size_t)blockIdx.x * node_stride;
+    int* nkey = W.key + (size_t)blockIdx.x * node_stride;
+    int* table = W.table + (size_t)blockIdx.x * table_stride;
+    for (int q = blockIdx.x; q < B; q += gridDim.x) {
+        const double sx0 = io.starts[3 * q], sy0 = io.starts[3 * q + 1], sw0 = io.starts[3 * q + 2];
+        const double gx = io.goals[3 * q], gy = io.goals[3 * q + 1], gw = io.goals[3 * q + 2];
+        int status = -1, iter_num = 0, use_node_num = 0, n = 0, n_path = 0;
+        if (kOcc(g, occ, sx0, sy0, sw0) == 1) status = 1;                                  // kino_astar.cpp:86-90
+        else if (kOccXY(g, occ2, gx, gy, gw) == 1) status = 2;                             // :91-95
+        if (status < 0) {
+            {                                                                              // expanded_nodes.clear(): 16-byte stores (the row stride is a multiple of 16 ints)
+                int4* t4 = (int4*)table;
+                const int4 m1 = make_int4(-1, -1, -1, -1);
+                for (size_t t = lane; t < (W.table_len + 3) / 4; t += 64) t4[t] = m1;
+            }
+            // :97-109
+            const double w0 = kNormalizeAngle(sw0);
+            int id3[3];
+            const int key0 = kKey(g, P, sx0, sy0, w0, id3);
+            const double dx = sx0 - gx, dy = sy0 - gy;
+            const double f0 = P.lambda_heu * (P.tie_breaker * sqrt(dx * dx + dy * dy));
+            if (lane == 0) {
+                KNode nd; nd.sx = sx0; nd.sy = sy0; nd.syaw = w0; nd.g = 0.0; nd.f = f0; nd.in_v = 0.0; nd.in_steer = 0.0; nd.parent = -1; nd.flag = K_OPEN;
+                nodes[0] = nd;
+                nkey[0] = key0;
+                if (key0 >= 0) table[key0] = 0;
+            }
+            kHeapPush(heap, pos, 0, 0, f0, lane);
+            n = 1; use_node_num = 1;
+        }
+        while (status < 0) {
+            if (n == 0) { status = 3; break; }                                             // :111, :233
+            const int cur = kuni(heap[0].id);
+            const KNode cn = nodes[cur];
+            const double cx = kuni(cn.sx), cy = kuni(cn.sy), cw = kuni(cn.syaw), cg = kuni(cn.g), civ = kuni(cn.in_v), cis = kuni(cn.in_steer);
+            {
+                const double dx = cx - gx, dy = cy - gy;
+                if (sqrt(dx * dx + dy * dy) < P.oneshot_range) {                           // :115-127, asignShotTraj kino_astar.h:242-271
+                    const double from[3] = {cx, cy, cw}, to[3] = {gx, gy, gw};
+                    KDubins path;
+                    kDubinsBetween(P, from, to, path);
+                    const double len = P.rho * (path.len[0] + path.len[1] + path.len[2]);
+                    int M = 0;
+                    for (double l = 0.0; l <= len && M < (1 << 20); l += P.coll_interval) M++;      // `for (l = 0; l <= len; l += collision_interval)`
+                    bool blocked = false;
+                    {
+                        double l = 0.0; int k = 0;
+                        for (int s = lane; s < M; s += 64) {
+                            for (; k < s; k++) l += P.coll_interval;                       // the running sum the reference forms
+                            double sp[3];
+                            kDubinsInterpolate(P, from, to, path, l / len, sp);
+                            if (kOccXY(g, occ2, sp[0], sp[1], sp[2]) == 1) blocked = true;
+                        }
+                    }
+                    if (!__ballot(blocked) && M > 0) {
+                        // retrievePath (kino_astar.h:273-292): root .. cur, then the shot samples
+                        int depth = 0;
+                        if (lane == 0) { for (int v = cur; v >= 0; v = nodes[v].parent) depth++; }
+                        depth = kuni(depth);
+                        n_path = depth + M;
+                        double* out = io.paths + (size_t)q * io.path_cap * 3;
+                        if (lane == 0) {
+                            int at = depth - 1;
+                            for (int v = cur; v >= 0; v = nodes[v].parent, at--) {
+                                if (at < io.path_cap) { out[3 * at] = nodes[v].sx; out[3 * at + 1] = nodes[v].sy; out[3 * at + 2] = nodes[v].syaw; }
+                            }
+                        }
+                        double l = 0.0; int k = 0;
+                        for (int s = lane; s < M; s += 64) {
+                            for (; k < s; k++) l += P.coll_interval;
+                            double sp[3];
+                            kDubinsInterpolate(P, from, to, path, l / len, sp);
+                            if (depth + s < io.path_cap) { out[3 * (depth + s)] = sp[0]; out[3 * (depth + s) + 1] = sp[1]; out[3 * (depth + s) + 2] = sp[2]; }
+                        }
+                        status = 0;
+                        break;
+                    }
+                }
+            }
+            kHeapPop(heap, pos, n, lane);                                                  // :129-131
+            n--;
+            if (lane == 0) nodes[cur].flag = K_CLOSE;
+            if (io.expanded && iter_num < io.exp_cap && lane == 0) {
+                const int kk = nkey[cur];
+                int* e = io.expanded + ((size_t)q * io.exp_cap + iter_num) * 3;
+                const bool nanrow = kk >= P.nxy * P.nyawk;
+                const int cell = nanrow ? 0 : kk / P.nyawk;
+                e[0] = nanrow ? INT_MIN : cell / g.ny; e[1] = nanrow ? INT_MIN : cell % g.ny; e[2] = nanrow ? kk - P.nxy * P.nyawk : kk % P.nyawk;
+            }
+            iter_num++;
+            if (io.max_expand > 0 && iter_num >= io.max_expand) { status = 5; break; }
+            // ---- the primitives of this node, one per lane (:147-195)
+            bool act = false;
+            double px = 0.0, py = 0.0, pw = 0.0, tg = 0.0, tf = 0.0, iv = 0.0, is = 0.0;
+            int key = -1, pre = -1, pre_flag = 0;
+            double pre_g = 0.0;
+            if (lane < P.n_inputs) {
+                iv = P.in_v[lane]; is = P.in_steer[lane];
+                const double tand = P.in_tan[lane];
+                kStateTransit(P, cx, cy, cw, iv, is, tand, P.time_interval, px, py, pw);
+                if (isInMap<double>(g, px, py, pw)) {                                      // :154-158
+                    int id3[3];
+                    key = kKey(g, P, px, py, pw, id3);
+                    pre = key >= 0 ? table[key] : -1;                                      // :163-164
+                    if (pre >= 0) { pre_flag = nodes[pre].flag; pre_g = nodes[pre].g; }
+                    bool closed = pre >= 0 && pre_flag == K_CLOSE;                         // :166-169
+                    int occv = 0;
+                    const int nt = P.in_nt[lane];
+                    for (int s = 0; s < nt && !closed; s++) {                              // :171-185
+                        double xt, yt, wt;
+                        kStateTransit(P, cx, cy, cw, iv, is, tand, P.in_t[lane][s], xt, yt, wt);
+                        occv = kOccXY(g, occ2, xt, yt, wt);
+                        if (occv == 1) break;
+                    }
+                    if (!closed && occv != 1) {
+                        const double arc = iv * P.time_interval;
+                        double t = 0.0;                                                    // :187-195
+                        t += P.w_r2 * arc;
+                        t += P.w_so2 * fabs(is) * arc;
+                        t += P.w_vch * fabs(iv - civ);
+                        t += P.w_dch * fabs(is - cis);
+                        t += P.w_sigma * kTerrainSig(g, px, py, pw);
+                        t += cg;
+                        tg = t;
+                        const double dx = px - gx, dy = py - gy;
+                        tf = tg + P.lambda_heu * (P.tie_breaker * sqrt(dx * dx + dy * dy));
+                        act = true;
+                    }
+                }
+            }
+            // ---- the primitives meet the table in their order (:197-229).  A primitive whose key an EARLIER primitive of this expansion has
+            // inserted or relaxed re-reads the table; the others use what their lane fetched above.
+            unsigned long long todo = __ballot(act);
+            unsigned long long done = 0;
+            while (todo) {
+                const int i = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int ki = klane(key, i);
+                if (ki < 0) { status = 6; break; }
+                int pn = klane(pre, i), pf = klane(pre_flag, i);
+                double pg = klane(pre_g, i);
+                if (__ballot(((done >> lane) & 1ull) && key == ki)) {
+                    pn = kuni(table[ki]);
+                    if (pn >= 0) { const KNode t = nodes[pn]; pf = kuni(t.flag); pg = kuni(t.g); }
+                }
+                const double ig = klane(tg, i), ifs = klane(tf, i);
+                if (pn >= 0 && pf == K_CLOSE) continue;
+                KNode nd;                                                                  // (wave-uniform: the successor of primitive i)
+                nd.sx = klane(px, i); nd.sy = klane(py, i); nd.syaw = klane(pw, i); nd.g = ig; nd.f = ifs; nd.in_v = klane(iv, i); nd.in_steer = klane(is, i);
+                nd.parent = cur; nd.flag = K_OPEN;
+                if (pn < 0) {                                                              // :197-217
+                    pn = use_node_num;
+                    if (lane == 0) { nodes[pn] = nd; nkey[pn] = ki; table[ki] = pn; }
+                    kHeapPush(heap, pos, n, pn, ifs, lane);
+                    n++;
+                    use_node_num++;
+                    done |= 1ull << i;
+                    if (use_node_num == P.allocate_num) { status = 4; break; }             // :212-216
+                } else if (pf == K_OPEN) {                                                 // :218-229
+                    if (ig < pg) {
+                        if (lane == 0) {
+                            nodes[pn] = nd;
+                            heap[pos[pn]].f = ifs;                                         // the key the comparisons see from now on; no re-heapify (as the reference)
+                        }
+                        done |= 1ull << i;
+                    }
+                }
+            }
+        }
+        if (lane == 0) { io.status[q] = status; io.n_path[q] = n_path; io.iter_num[q] = iter_num; io.use_node_num[q] = use_node_num; }
+    }
+}
+
+}  // namespace
+
+struct uph_kino {
+    uph_map* map = nullptr;
+    int device = 0;
+    KinoDev P;
+    int slots = 0;
+    size_t node_stride = 0, heap_stride = 0, table_stride = 0;
+    void *d_P = nullptr, *d_nodes = nullptr, *d_heap = nullptr, *d_pos = nullptr, *d_key = nullptr, *d_table = nullptr;
+    void *d_io[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t io_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double last_ms = 0.0;
+};
+
+extern "C" {
+
+int uph_kino_create(uph_map* m, const uph_kino_params* kp, int32_t slots, uph_kino** out) {
+    if (!m || !kp || !out || slots < 0) { setError("uph_kino_create: bad arguments"); return UPH_ERR_INVALID; }
+    const GridDev g = uphMapGrid(m);
+    if (g.nx_hold != g.nx) { setError("uph_kino_create: tile maps are not searched (the search needs the whole grid's occupancy)"); return UPH_ERR_INVALID; }
+    if (!(kp->yaw_resolution > 0) || !(kp->time_interval > 0) || !(kp->collision_interval > 0) || !(kp->max_vel > 0) || !(kp->max_steer > 0) || !(kp->wheel_base > 0)) {
+        setError("uph_kino_create: parameters must be positive"); return UPH_ERR_INVALID;
+    }
+    KHIPCHK(hipSetDevice(uphMapDevice(m)));
+    uph_kino* k = new uph_kino();
+    k->map = m; k->device = uphMapDevice(m);
+    KinoDev& P = k->P;
+    std::memset(&P, 0, sizeof(P));
+    P.yaw_inv = 1.0 / kp->yaw_resolution;                                   // kino_astar.cpp:31
+    P.lambda_heu = kp->lambda_heu; P.w_r2 = kp->weight_r2; P.w_so2 = kp->weight_so2; P.w_vch = kp->weight_v_change; P.w_dch = kp->weight_delta_change; P.w_sigma = kp->weight_sigma;
+    P.time_interval = kp->time_interval; P.coll_interval = kp->collision_interval; P.oneshot_range = kp->oneshot_range; P.wheel_base = kp->wheel_base;
+    P.rho = kp->wheel_base / std::tan(kp->max_steer);                       // :33
+    P.tie_breaker = 1.0 + 1.0 / 10000;                                      // kino_astar.h:127
+    P.nxy = g.nx * g.ny;
+    P.allocate_num = g.nx * g.ny;                                           // setEnvironment: getXYNum nodes
+    {
+        const double top = std::floor((3.14159265358979323846 + 3.14159265358979323846) * P.yaw_inv);
+        if (!(top >= 0 && top < 4096)) { delete k; setError("uph_kino_create: yaw_resolution gives more than 4096 yaw bins"); return UPH_ERR_LIMIT; }
+        P.nyawk = (int)top + 1;
+    }
+    // the primitives and their collision sample times, by the reference's own loops (kino_astar.cpp:138-145, 173-175)
+    int ni = 0;
+    for (double v = 0; v <= kp->max_vel + 1e-3; v += 0.5 * kp->max_vel)
+        for (double steer = -kp->max_steer; steer <= kp->max_steer + 1e-3; steer += 0.5 * kp->max_steer) {
+            if (ni >= K_MAX_INPUTS) { delete k; setError("uph_kino_create: more than 64 motion primitives"); return UPH_ERR_LIMIT; }
+            P.in_v[ni] = v; P.in_steer[ni] = steer; P.in_tan[ni] = std::tan(steer);
+            const double arc = v * kp->time_interval;
+            const double temp_ct = kp->collision_interval / arc * kp->time_interval;
+            int nt = 0;
+            for (double t = temp_ct; t <= kp->time_interval + 1e-3; t += temp_ct) {
+                if (nt >= K_MAX_TSAMP) { delete k; setError("uph_kino_create: more than 8 collision samples per primitive (collision_interval too fine)"); return UPH_ERR_LIMIT; }
+                P.in_t[ni][nt++] = t;
+            }
+            P.in_nt[ni] = nt;
+            ni++;
+        }
+    P.n_inputs = ni;
+    if (slots == 0) {
+        hipDeviceProp_t prop;
+        KHIPCHK(hipGetDeviceProperties(&prop, k->device));
+        slots = prop.multiProcessorCount * 8;                               // eight waves per CU: the search is latency-bound, the CU has slots to spare
+    }
+    k->slots = slots;
+    k->node_stride = (size_t)P.allocate_num;
+    k->heap_stride = (size_t)P.allocate_num + 1;
+    k->table_stride = (((size_t)P.nxy + 1) * P.nyawk + 15) & ~(size_t)15;
+    auto fail = [&](const char* what) { setError(std::string("uph_kino_create: hipMalloc(") + what + ") failed"); uph_kino_destroy(k); return UPH_ERR_HIP; };
+    if (hipMalloc(&k->d_P, sizeof(KinoDev)) != hipSuccess) return fail("params");
+    if (hipMalloc(&k->d_nodes, sizeof(KNode) * k->node_stride * slots) != hipSuccess) return fail("nodes");
+    if (hipMalloc(&k->d_heap, sizeof(KHeap) * k->heap_stride * slots) != hipSuccess) return fail("heap");
+    if (hipMalloc(&k->d_pos, sizeof(int) * k->node_stride * slots) != hipSuccess) return fail("pos");
+    if (hipMalloc(&k->d_key, sizeof(int) * k->node_stride * slots) != hipSuccess) return fail("key");
+    if (hipMalloc(&k->d_table, sizeof(int) * k->table_stride * slots) != hipSuccess) return fail("table");
+    if (hipMemcpy(k->d_P, &P, sizeof(KinoDev), hipMemcpyHostToDevice) != hipSuccess) { setError("uph_kino_create: hipMemcpy failed"); uph_kino_destroy(k); return UPH_ERR_HIP; }
+    if (hipEventCreate(&k->e0) != hipSuccess || hipEventCreate(&k->e1) != hipSuccess) { setError("uph_kino_create: hipEventCreate failed"); uph_kino_destroy(k); return UPH_ERR_HIP; }
+    *out = k;
+    return UPH_OK;
+}
+
+void uph_kino_destroy(uph_kino* k) {
+    if (!k) return;
+    hipSetDevice(k->device);
+    hipFree(k->d_P); hipFree(k->d_nodes); hipFree(k->d_heap); hipFree(k->d_pos); hipFree(k->d_key); hipFree(k->d_table);
+    for (int i = 0; i < 8; i++) hipFree(k->d_io[i]);
+    if (k->e0) hipEventDestroy(k->e0);
+    if (k->e1) hipEventDestroy(k->e1);
+    delete k;
+}
+
+int uph_kino_slots(const uph_kino* k) { return k ? k->slots : UPH_ERR_INVALID; }
+int uph_kino_primitives(const uph_kino* k) { return k ? k->P.n_inputs : UPH_ERR_INVALID; }
+
+int uph_kino_plan_batch(uph_kino* k, int32_t B, const double* starts, const double* goals, int32_t path_cap, double* paths, int32_t* n_path, int32_t* status,
+                        int32_t* iter_num, int32_t* use_node_num, int32_t max_expand, int32_t exp_cap, int32_t* expanded) {
+    if (!k || B <= 0 || !starts || !goals || path_cap < 0 || (path_cap > 0 && !paths) || !n_path || !status || exp_cap < 0 || (exp_cap > 0 && !expanded)) {
+        setError("uph_kino_plan_batch: bad arguments"); return UPH_ERR_INVALID;
+    }
+    KHIPCHK(hipSetDevice(k->device));
+    const size_t need[8] = {sizeof(double) * 3 * (size_t)B, sizeof(double) * 3 * (size_t)B, sizeof(double) * 3 * (size_t)B * (size_t)std::max(1, path_cap), sizeof(int) * (size_t)B,
+                            sizeof(int) * (size_t)B, sizeof(int) * (size_t)B, sizeof(int) * (size_t)B, sizeof(int) * 3 * (size_t)B * (size_t)std::max(1, exp_cap)};
+    for (int i = 0; i < 8; i++) {
+        if (need[i] <= k->io_cap[i]) continue;
+        if (k->d_io[i]) hipFree(k->d_io[i]);
+        k->d_io[i] = nullptr; k->io_cap[i] = 0;
+        const size_t want = need[i] + need[i] / 4 + 256;
+        if (hipMalloc(&k->d_io[i], want) != hipSuccess) { setError("uph_kino_plan_batch: hipMalloc failed"); return UPH_ERR_HIP; }
+        k->io_cap[i] = want;
+    }
+    KHIPCHK(hipMemcpy(k->d_io[0], starts, need[0], hipMemcpyHostToDevice));
+    KHIPCHK(hipMemcpy(k->d_io[1], goals, need[1], hipMemcpyHostToDevice));
+    KinoIO io;
+    io.starts = (const double*)k->d_io[0]; io.goals = (const double*)k->d_io[1];
+    io.paths = (double*)k->d_io[2]; io.path_cap = path_cap;
+    io.n_path = (int*)k->d_io[3]; io.status = (int*)k->d_io[4]; io.iter_num = (int*)k->d_io[5]; io.use_node_num = (int*)k->d_io[6];
+    io.expanded = exp_cap > 0 ? (int*)k->d_io[7] : nullptr; io.exp_cap = exp_cap;
+    io.max_expand = max_expand;
+    KinoWork W;
+    W.nodes = (KNode*)k->d_nodes; W.heap = (KHeap*)k->d_heap; W.pos = (int*)k->d_pos; W.key = (int*)k->d_key; W.table = (int*)k->d_table;
+    W.table_len = ((size_t)k->P.nxy + 1) * k->P.nyawk;
+    const char *occ = nullptr, *occ2 = nullptr;
+    uphMapOcc(k->map, &occ, &occ2);
+    const int grid = std::min((int)B, k->slots);
+    KHIPCHK(hipEventRecord(k->e0, 0));
+    hipLaunchKernelGGL(uph_kino_kernel, dim3(grid), dim3(64), 0, 0, uphMapGrid(k->map), occ, occ2, (const KinoDev*)k->d_P, W, k->node_stride, k->heap_stride, k->table_stride, io, (int)B);
+    KHIPCHK(hipGetLastError());
+    KHIPCHK(hipEventRecord(k->e1, 0));
+    KHIPCHK(hipDeviceSynchronize());
+    float ms = 0.f;
+    KHIPCHK(hipEventElapsedTime(&ms, k->e0, k->e1));
+    k->last_ms = ms;
+    if (path_cap > 0) KHIPCHK(hipMemcpy(paths, k->d_io[2], sizeof(double) * 3 * (size_t)B * path_cap, hipMemcpyDeviceToHost));
+    KHIPCHK(hipMemcpy(n_path, k->d_io[3], need[3], hipMemcpyDeviceToHost));
+    KHIPCHK(hipMemcpy(status, k->d_io[4], need[4], hipMemcpyDeviceToHost));
+    if (iter_num) KHIPCHK(hipMemcpy(iter_num, k->d_io[5], need[5], hipMemcpyDeviceToHost));
+    if (use_node_num) KHIPCHK(hipMemcpy(use_node_num, k->d_io[6], need[6], hipMemcpyDeviceToHost));
+    if (exp_cap > 0) KHIPCHK(hipMemcpy(expanded, k->d_io[7], sizeof(int) * 3 * (size_t)B * exp_cap, hipMemcpyDeviceToHost));
+    return UPH_OK;
+}
+
+int uph_kino_stats(uph_kino* k, double* kernel_ms) { if (!k || !kernel_ms) return UPH_ERR_INVALID; *kernel_ms = k->last_ms; return UPH_OK; }
+
+}  // extern "C"

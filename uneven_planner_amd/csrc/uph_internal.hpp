@@ -18,6 +18,8 @@ struct UphPtr {                 // non-owning view of a scratch slot
     template <class T> T* as() { return (T*)p; }
 };
 uph::GridDev uphMapGrid(const uph_map* m);
+// device occupancy layers of the map (uneven_map.cpp:170-179): occ [ncell], occ_r2 [nx * ny]; read by the front-end search (kino_search.hip)
+void uphMapOcc(const uph_map* m, const char** occ, const char** occ_r2);
 
 // scope guards for the temporaries of the extern "C" entry points: every early return (HIPCHK) releases them
 struct UphDevTmp {

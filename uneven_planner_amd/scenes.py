@@ -89,6 +89,32 @@ def random_problems(n, seed0=1000, half=4.5, dmin=3.0, dmax=10.0, occ_r2=None, g
     return out
 
 
+def random_queries(n, seed0=1000, half=4.5, dmin=3.0, dmax=10.0, occ_r2=None, grid=None):
+    """start / goal poses of random_problems' protocol (same streams, same acceptance) without the initial-path stage: (n, 3), (n, 3) --
+    the inputs of the front-end search (KinoAstar::plan)"""
+    S, G = np.zeros((n, 3)), np.zeros((n, 3))
+    for i in range(n):
+        rng = np.random.Generator(np.random.PCG64(seed0 + i))
+        while True:
+            s = np.array([rng.uniform(-half, half), rng.uniform(-half, half), rng.uniform(-math.pi, math.pi)])
+            g = np.array([rng.uniform(-half, half), rng.uniform(-half, half), rng.uniform(-math.pi, math.pi)])
+            d = math.hypot(g[0] - s[0], g[1] - s[1])
+            if not (dmin <= d <= dmax):
+                continue
+            if occ_r2 is not None and grid is not None:
+                nx, ny, res, ox, oy = grid
+                ok = True
+                for p in (s, g):
+                    ix, iy = int(math.floor((p[0] - ox) / res)), int(math.floor((p[1] - oy) / res))
+                    if ix < 0 or iy < 0 or ix >= nx or iy >= ny or occ_r2[ix * ny + iy]:
+                        ok = False
+                if not ok:
+                    continue
+            S[i], G[i] = s, g
+            break
+    return S, G
+
+
 def batch_share(total, rank, world):
     """strong-scaling split of ONE batch over the ranks (configs[4]): rank r solves problems [lo, lo + count) of the batch"""
     per = -(-int(total) // int(world))
