@@ -28,6 +28,34 @@ BYTES_PER_SAMPLE_EVAL = 47 * 8      # 24 s gather + 14 s duals/sca
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+KERNEL_SOURCES = ("unevenhip.hip", "solver_program.hpp", "terrain_dev.hpp", "uph_common.hpp", "minco_op_host.hpp")
+
+
+def kernel_sources_sha():
+    """sha1 over the sources of the solve kernel: what a committed counter pass must have been taken from to describe this build"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "uneven_planner_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_counters(batch):
+    """the committed counter pass (profiles/pmc_traffic.json, written by tools/profile.sh) if it describes THIS kernel and batch size, else (None, why)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    if int(t.get("batch", -1)) != int(batch):
+        return None, "the committed counter pass (%s) is for B = %s, not for this batch size" % (t.get("tag"), t.get("batch"))
+    if t.get("kernel_src_sha") != kernel_sources_sha():
+        return None, "STALE: the committed counter pass (%s, kernel sources %s) is not of this build's kernel sources (%s) -- re-run tools/profile.sh" % (
+            t.get("tag"), t.get("kernel_src_sha"), kernel_sources_sha())
+    return t, None
+
+
 def pmc_traffic(batch, stream_bytes):
     """HBM-side bytes per solve step from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by tools/profile.sh;
     separate --pmc passes for FETCH_SIZE and WRITE_SIZE, both in KiB).  Calibration on known-byte microkernels in THIS kernel's
@@ -36,16 +64,12 @@ def pmc_traffic(batch, stream_bytes):
     writes at 1.  The solve kernel's contiguous reads are the L-BFGS history rows and the per-sample duals / scales
     (`stream_bytes`, algorithmic): their uncounted half is added back; gathers and writes are taken as counted.
     None when no PMC summary for this batch size is committed."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        if int(t["batch"]) != int(batch):
-            return None
-        fetch = t["fetch_kib"] * 1024.0 / max(1, t["launches"])
-        write = t["write_kib"] * 1024.0 / max(1, t["launches"])
-        return fetch + min(fetch, 0.5 * stream_bytes) + write, t.get("tag", "profiles/pmc_traffic.json")
-    except Exception:
+    t, why = pmc_counters(batch)
+    if t is None:
         return None
+    fetch = t["fetch_kib"] * 1024.0 / max(1, t["launches"])
+    write = t["write_kib"] * 1024.0 / max(1, t["launches"])
+    return fetch + min(fetch, 0.5 * stream_bytes) + write, t.get("tag", "profiles/pmc_traffic.json")
 
 
 def spawn_ranks(n, argv):
@@ -318,6 +342,26 @@ def main():
         bd["note"] = "uph_optimize_batch wall clock (upload + initScaling + solve + download of x, c_xy, c_yaw), pageable host arrays, best of the repeats"
         extras["boundary"] = bd
         del bo
+        # the front end that produces the back-end's inputs.  KinoAstar::plan (kino_astar.cpp:67-236) for the start / goal pairs
+        # of the batch's first problems (same streams, same acceptance), one wave64 per query (csrc/kino_search.hip); the CPU restatement is timed
+        # in the cpu_baseline leg below
+        try:
+            fq = min(2048, args.batch)
+            S_, G_ = scenes.random_queries(fq, seed0=1000, occ_r2=m.occ_r2_buffer, grid=gridinfo)
+            ka = U.KinoAstar(m)
+            ka.plan_batch(S_[:64], G_[:64], path_cap=1)
+            fe = {"slots": ka.slots, "primitives": ka.n_primitives}
+            for nq in (1, 256, fq):
+                t1 = time.perf_counter()
+                r_ = ka.plan_batch(S_[:nq], G_[:nq], path_cap=512)
+                wall = time.perf_counter() - t1
+                fe["B%d" % nq] = {"queries_per_s": nq / wall, "ms_per_call": wall * 1e3, "kernel_ms": ka.stats()["kernel_ms"], "found": float(np.mean([q_["status"] == 0 for q_ in r_])),
+                                  "expansions_per_query": float(np.mean([q_["iter_num"] for q_ in r_])), "M_expansions_per_s": float(np.sum([q_["iter_num"] for q_ in r_])) / wall / 1e6}
+            extras["front_end"] = fe
+            extras["_front_end_queries"] = (S_, G_)
+            del ka
+        except Exception as e:
+            extras["front_end"] = {"error": repr(e)}
     opt.upload(probs)
 
     kernel_ms, prepare_ms, evals, sample_evals, iters, hist_bytes = [], [], 0, 0, 0, 0
@@ -379,8 +423,15 @@ def main():
         avg_ms = float(np.mean(kernel_ms))
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         tr = None if km2 else pmc_traffic(args.batch, hist_bytes / K + sample_evals * 14 * 8 / K)
-        traffic, traffic_src = (tr[0], "committed rocprofv3 --pmc passes of this command (%s), not measured in this run" % tr[1]) if tr else \
-                               (None, "no committed PMC pass for this workload / batch size (profiles/pmc_traffic.json holds B = 16384 hill only)")
+        pc, pc_why = (None, "km2 workload: no committed counter pass") if km2 else pmc_counters(args.batch)
+        traffic, traffic_src = (tr[0], "committed rocprofv3 --pmc passes of this command (%s), not measured in this run" % tr[1]) if tr else (None, pc_why)
+        # the bound that actually binds: VALU issue.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over all waves; per SIMD
+        # (4 per CU, 256 CUs) and per launch of the committed pass, against that pass's own launch duration at the 2.4 GHz shader clock
+        valu_busy = wait_frac = None
+        if pc is not None and pc.get("sq_active_inst_valu") and pc.get("launch_ms"):
+            simd_cycles = 256 * 4 * pc["launch_ms"] * 1e-3 * 2.4e9
+            valu_busy = pc["sq_active_inst_valu"] * 4.0 / max(1, pc["launches"]) / simd_cycles
+            wait_frac = pc["sq_wait_any"] / pc["sq_wave_cycles"] if pc.get("sq_wave_cycles") else None
         # 7 of the 47 doubles per sample are the residual stores of SURVEY.md 8d's definition, which the solve kernel performs once per L-BFGS
         # pass, not per evaluation: the fraction without them is reported next to the defined one
         moved_bytes = (sample_evals * (bytes_per_sample - 7 * 8) + hist_bytes + iters * 2 * 8 * (n_sum / max(1, args.batch))) / K
@@ -403,8 +454,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "uph_solver_kernel<%s,2> (ALM/L-BFGS solve)" % ("128,2" if args.batch >= 2304 else ("256,2" if args.batch >= 512 else "256,1")), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "frac_without_unwritten_residuals": moved_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "sample_bytes_per_launch": sample_evals * bytes_per_sample / K, "history_bytes_per_launch": hist_bytes / K},
+                         "sample_bytes_per_launch": sample_evals * bytes_per_sample / K, "history_bytes_per_launch": hist_bytes / K,
+                         "valu_busy": valu_busy, "wave_wait_frac": wait_frac,
+                         "valu_busy_source": ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch x 2.4 GHz) of the committed counter pass %s (git %s, kernel sources %s, launch %.1f ms)" % (
+                             pc.get("tag"), pc.get("git_head"), pc.get("kernel_src_sha"), pc.get("launch_ms", float("nan")))) if pc is not None else pc_why,
+                         "kernel_src_sha": kernel_sources_sha()},
         }
+        res["converged_traj_opts_per_s"] = value * res["converged_frac"]      # solves that END converged (ret_code 0); the rest hit the ALM pass cap like the reference's
+        fe_queries = extras.pop("_front_end_queries", None)
         res.update(extras)
         if pipelined:
             res["pipelined"] = pipelined
@@ -445,13 +502,34 @@ def main():
                 sel = (its >= lo_) & (its < hi_)
                 if sel.any():
                     rows.append({"iters": [lo_, hi_ if hi_ < (1 << 30) else None], "n": int(sel.sum()), "waypoints_le_1e-4": float((relx[sel] <= 1e-4).mean()), "median": float(np.median(relx[sel]))})
-            res["parity_floor"] = {"sample": nsamp, "same_ret": float(np.mean([d_["ret"] == r_["ret"] for d_, r_ in zip(devs, oref)])),
+            drift = None
+            if not km2:
+                # the oracle's own reproducibility on the same sample (rebuilt with -ffp-contract=fast -march=native, tests/sensitivity.py), so that the
+                # line shows all three converged rates, the discordant pairs BOTH ways and a sign test on the final costs: a one-sided drift would show
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tests"))
+                    import sensitivity
+                    fma = sensitivity.solve_with_fma_oracle(m.map_buffer, probs[:nsamp])
+                    drift = sensitivity.drift_stats(oref, fma, devs)
+                except Exception as e:      # (no compiler on the box: the rest of the line stands)
+                    drift = {"error": repr(e)}
+            res["parity_floor"] = {"sample": nsamp, "same_ret": float(np.mean([d_["ret"] == r_["ret"] for d_, r_ in zip(devs, oref)])), "drift": drift,
                                    "waypoints_le_1e-4": float((relx <= 1e-4).mean()), "converged_frac_device_on_sample": float(np.mean([d_["ret"] == 0 for d_ in devs])),
                                    "by_oracle_lbfgs_iters": rows,
                                    "note": "device vs CPU oracle, final way-points, relative inf-norm; the oracle rebuilt with FMA contraction shows the same decay (profiles/*parity_buckets.json)" +
                                            ("; km2: the 1e9-cell grid stays on the device, the oracle runs on a window of cells translated to its own origin -- positions 400 m from the map origin carry "
                                             "1e-13 of relative rounding in (x - origin) where the window has 1e-15, which seeds the optimiser's divergence two decades higher than on the hill scene "
                                             "(first evaluations agree to 1e-9, tests/test_gpu_km2.py)" if km2 else "")}
+            if fe_queries is not None and "front_end" in res and "error" not in res["front_end"]:
+                # the front end on the host: the oracle's restatement of KinoAstar::plan, single thread, first 64 queries of the same list
+                og.set_occ(m.occ_buffer, m.occ_r2_buffer)
+                ok_ = O.OracleKinoAstar(og)
+                t0 = time.perf_counter()
+                fr = [ok_.plan(s_, g_) for s_, g_ in zip(fe_queries[0][:64], fe_queries[1][:64])]
+                fdt = time.perf_counter() - t0
+                res["front_end"]["cpu"] = {"ms_per_goal": fdt * 1e3 / 64, "queries_per_s": 64 / fdt, "cores": 1, "kind": "port", "sample": "first 64 queries, CPU oracle (oracle/kino_astar.hpp), %.2f s" % fdt,
+                                           "expansions_per_query": float(np.mean([q_["iter_num"] for q_ in fr])), "found": float(np.mean([q_["status"] == 0 for q_ in fr]))}
+                res["front_end"]["gpu_over_cpu_per_goal"] = res["front_end"]["B%d" % min(2048, args.batch)]["queries_per_s"] / (64 / fdt)
             if args.cpu_threads > 1 and not km2:
                 # context only: the reference is single-threaded; this is "one trajectory per host thread" on the same box
                 from concurrent.futures import ThreadPoolExecutor

@@ -82,3 +82,54 @@ def bucket_table(ref, other, edges=BUCKET_EDGES):
         rows.append(dict(lo=lo, hi=hi, n=int(m.sum()), x_le_1e4=float((dx[m] <= 1e-4).mean()), c_le_1e4=float((dc[m] <= 1e-4).mean()),
                          x_median=float(np.median(dx[m])), x_max=float(dx[m].max())))
     return rows
+
+
+# ---- directional drift: is the device's disagreement with the oracle one-sided? ---------------------------------------
+def _binom_two_sided(k, n):
+    """exact two-sided binomial p-value for k successes of n at p = 1/2 (McNemar's exact test / the sign test)"""
+    if n == 0:
+        return 1.0
+    from math import comb
+    k = min(k, n - k)
+    return float(min(1.0, 2.0 * sum(comb(n, i) for i in range(k + 1)) / 2.0 ** n))
+
+
+def paired_counts(ref, other):
+    """ref / other: result lists of the SAME problems.  Converged = ret == 0 (alm_traj_opt.cpp:259-262).  b = other converged where ref did not,
+    c = ref converged where other did not (McNemar's discordant pairs); cost sign test over the pairs whose final costs differ"""
+    cr = np.array([r["ret"] == 0 for r in ref]); co = np.array([o["ret"] == 0 for o in other])
+    b, c = int((co & ~cr).sum()), int((cr & ~co).sum())
+    dcost = np.array([o["cost"] - r["cost"] for r, o in zip(ref, other)])
+    lo, hi = int((dcost < 0).sum()), int((dcost > 0).sum())
+    return dict(n=len(ref), converged_ref=float(cr.mean()), converged_other=float(co.mean()), other_only=b, ref_only=c, mcnemar_p=_binom_two_sided(b, b + c),
+                same_ret=float(np.mean([r["ret"] == o["ret"] for r, o in zip(ref, other)])),
+                cost_lower=lo, cost_higher=hi, cost_sign_p=_binom_two_sided(lo, lo + hi))
+
+
+def drift_stats(ref, fma, dev):
+    """the three-way statement: oracle, oracle rebuilt with FMA contraction (its own reproducibility floor) and the device on the same problems"""
+    d, f = paired_counts(ref, dev), paired_counts(ref, fma)
+    return dict(n=d["n"], converged_frac=dict(oracle=d["converged_ref"], oracle_fma=f["converged_other"], device=d["converged_other"]),
+                device_vs_oracle=dict(device_only=d["other_only"], oracle_only=d["ref_only"], mcnemar_p=d["mcnemar_p"], same_ret=d["same_ret"],
+                                      cost_lower=d["cost_lower"], cost_higher=d["cost_higher"], cost_sign_p=d["cost_sign_p"]),
+                fma_vs_oracle=dict(fma_only=f["other_only"], oracle_only=f["ref_only"], mcnemar_p=f["mcnemar_p"], same_ret=f["same_ret"],
+                                   cost_lower=f["cost_lower"], cost_higher=f["cost_higher"], cost_sign_p=f["cost_sign_p"]))
+
+
+def assert_no_directional_drift(st, what=""):
+    """The device may disagree with the oracle as often as the oracle disagrees with its own FMA rebuild -- the optimiser is chaotic -- but not in
+    ONE direction.  Converged rate: |device - oracle| <= |fma - oracle| + 2 SE, SE = sqrt(b + c) / n of the paired difference (McNemar);
+    same return code: device >= floor - 2 SE of the difference of the two proportions; final cost: the sign test must not reject at 1e-3 unless the
+    FMA pair's does too (the oracle drifting against itself is not the device's doing)."""
+    n = st["n"]
+    dv, fm = st["device_vs_oracle"], st["fma_vs_oracle"]
+    d_dev = abs(dv["device_only"] - dv["oracle_only"]) / n
+    d_fma = abs(fm["fma_only"] - fm["oracle_only"]) / n
+    se = np.sqrt(dv["device_only"] + dv["oracle_only"]) / n
+    assert d_dev <= d_fma + 2.0 * se + 1e-12, "%s: converged rate drifts one way: device-only %d vs oracle-only %d of %d (FMA pair: %d vs %d)" % (
+        what, dv["device_only"], dv["oracle_only"], n, fm["fma_only"], fm["oracle_only"])
+    pd_, pf_ = dv["same_ret"], fm["same_ret"]
+    se_ret = np.sqrt((pd_ * (1 - pd_) + pf_ * (1 - pf_)) / n)
+    assert pd_ >= pf_ - 2.0 * se_ret - 1e-12, "%s: same return code %.3f (device) vs %.3f (floor), 2 SE = %.3f" % (what, pd_, pf_, 2 * se_ret)
+    assert dv["cost_sign_p"] >= 1e-3 or fm["cost_sign_p"] < 1e-3, "%s: final cost is systematically %s than the oracle's (%d lower, %d higher, p = %.1e; FMA pair %d / %d)" % (
+        what, "lower" if dv["cost_lower"] > dv["cost_higher"] else "higher", dv["cost_lower"], dv["cost_higher"], dv["cost_sign_p"], fm["cost_lower"], fm["cost_higher"])

@@ -127,3 +127,119 @@ def test_cpp_adapter_compiles(tmp_path):
     src = tmp_path / "consumer.cpp"
     src.write_text(CONSUMER)
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "a.o")])
+
+
+# ---- INTEGRATION.md's reference-side recipe, compiled against the reference's ACCESS RULES -------------------------------------------------
+# A stand-in for uneven_map/include/uneven_map/uneven_map.h:66-152 with the same member names in the same sections: parameters and buffers
+# PRIVATE (:68-110), the query interface public (:112-151).  Types the image lacks (Eigen, PCL, ROS) are minimal stand-ins with just the
+# members the snippets touch; what matters here is who may touch what.
+INTEGRATION_STUB = r"""
+#include <memory>
+#include <string>
+#include <vector>
+%(map_header)s
+namespace Eigen {
+struct Vector3d { double v[3] = {0, 0, 0}; double& operator()(int i) { return v[i]; } double operator()(int i) const { return v[i]; } double& operator[](int i) { return v[i]; } };
+struct Vector3i { int v[3] = {0, 0, 0}; int& operator()(int i) { return v[i]; } };
+}
+namespace pcl { struct PointXYZ { float x, y, z; }; template <class P> struct PointCloud { std::vector<P> points; }; }
+namespace ros { struct NodeHandle {}; }
+namespace uneven_planner {
+using std::string; using std::vector; using std::shared_ptr;
+struct RXS2 { double z = 0, sigma = 0, zbx = 0, zby = 0; };           // uneven_map.h:36-64: four doubles
+class UnevenMap
+{
+    private:                                                           // uneven_map.h:68-110
+        int             iter_num;
+        double          ellipsoid_x;
+        double          ellipsoid_y;
+        double          ellipsoid_z;
+        double          xy_resolution, xy_resolution_inv;
+        double          yaw_resolution, yaw_resolution_inv;
+        double          min_cnormal;
+        double          max_rho;
+        double          gravity;
+        double          mass;
+        Eigen::Vector3d map_origin;
+        Eigen::Vector3d map_size;
+        Eigen::Vector3d min_boundary;
+        Eigen::Vector3d max_boundary;
+        Eigen::Vector3i min_idx;
+        Eigen::Vector3i max_idx;
+        Eigen::Vector3i voxel_num;
+        string          map_file;
+        string          pcd_file;
+        vector<RXS2>    map_buffer;
+        vector<double>  c_buffer;
+        vector<char>    occ_buffer;
+        vector<char>    occ_r2_buffer;
+        bool            map_ready = false;
+    public:                                                            // uneven_map.h:112-151
+        UnevenMap() {}
+%(map_members)s
+        void init(ros::NodeHandle& nh);
+        bool constructMapInput() { return false; }
+        bool constructMap() { return true; }
+        typedef shared_ptr<UnevenMap> Ptr;
+};
+void UnevenMap::init(ros::NodeHandle& nh)
+{
+    (void)nh;
+    pcl::PointCloud<pcl::PointXYZ> cloudMapOrigin;                     // uneven_map.cpp:127-131
+%(map_init_read)s
+%(map_init_build)s
+    {
+%(multi_map_init)s
+    }
+}
+struct PlanManager                                                     // plan_manager.h:26-40: a friend of nobody
+{
+    UnevenMap::Ptr uneven_map;
+    uneven_hip::ALMTrajOpt traj_opt;
+    void init(ros::NodeHandle& nh)
+    {
+        uneven_map.reset(new UnevenMap);
+        uneven_map->init(nh);
+%(manager_init)s
+    }
+    void many(const std::vector<std::vector<uneven_hip::VecN<3>>>& paths, const uph_manager_params& manager_params)
+    {
+%(multi_manager)s
+        (void)plans; (void)reports;
+    }
+};
+}
+"""
+
+
+def _integration_snippets():
+    """fenced cpp blocks of INTEGRATION.md tagged `<!-- snippet: name -->`: in a diff block the `+` lines (verbatim, marker stripped), else all lines"""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    out = {}
+    for m in re.finditer(r"<!-- snippet: (\w+) -->\n```cpp\n(.*?)```", txt, flags=re.S):
+        lines = m.group(2).split("\n")
+        is_diff = any(ln.startswith("+") for ln in lines)
+        out[m.group(1)] = "\n".join((ln[1:] if is_diff else ln) for ln in lines if (ln.startswith("+") if is_diff else True))
+    return out
+
+
+def test_integration_recipe_compiles_against_private_members(tmp_path):
+    """the reference-side snippets of INTEGRATION.md 1 and 4(a) are compiled AS WRITTEN against a stand-in UnevenMap whose
+    parameters and buffers are private like the reference's -- a recipe that reads them from PlanManager does not build"""
+    import subprocess
+    sn = _integration_snippets()
+    for need in ("map_header", "map_init_read", "map_init_build", "manager_init", "multi_map_init", "multi_manager"):
+        assert need in sn and sn[need].strip(), "INTEGRATION.md lost its `%s` snippet" % need
+    hdr = [ln for ln in sn["map_header"].split("\n") if ln.strip().startswith("#include")]
+    members = [ln for ln in sn["map_header"].split("\n") if not ln.strip().startswith("#include")]
+    members.append("        std::vector<std::shared_ptr<uneven_hip::UnevenMapHandle>> gpu_maps;")       # the multi-GPU variant's member (INTEGRATION.md 4a, in prose)
+    src = INTEGRATION_STUB % dict(map_header="\n".join(hdr), map_members="\n".join(members), map_init_read=sn["map_init_read"], map_init_build=sn["map_init_build"],
+                                  manager_init=sn["manager_init"], multi_map_init=sn["multi_map_init"], multi_manager=sn["multi_manager"])
+    f = tmp_path / "recipe.cpp"
+    f.write_text(src)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wno-unused-variable", "-I", os.path.join(ROOT, "include"), "-c", str(f), "-o", str(tmp_path / "r.o")])
+    # ... and the check bites: the round-3 form of the recipe (PlanManager reading the private buffers) must NOT compile
+    bad = src.replace("        uneven_map->init(nh);\n", "        uneven_map->init(nh);\n        (void)uneven_map->map_buffer.data();\n", 1)
+    g = tmp_path / "bad.cpp"
+    g.write_text(bad)
+    assert subprocess.call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-c", str(g), "-o", str(tmp_path / "b.o")], stderr=subprocess.DEVNULL) != 0

@@ -130,7 +130,9 @@ def test_f32_lookups_and_solves_equal_the_oracle_on_the_rounded_grid(small_maps,
     floor, got = sensitivity.spread(ref, fma), sensitivity.spread(ref, out)
     print("km2-small floor", floor, "device", got)
     assert got["c_median"] <= 3.0 * floor["c_median"] + 1e-3 and got["x_median"] <= 3.0 * floor["x_median"] + 1e-3
-    assert got["same_ret"] >= floor["same_ret"] - 0.3
+    st = sensitivity.drift_stats(ref, fma, out)
+    print("km2-small drift", st)
+    sensitivity.assert_no_directional_drift(st, "km2-small")
 
 
 def test_grid_beyond_4GiB_is_addressed_correctly(oracle):

@@ -69,21 +69,31 @@ def test_map_build_edge_and_empty_cells(oracle):
     assert np.median(np.abs(dev[:, 0] - orc[:, 0])) < 1e-12
 
 
-def test_frontend_queries_match_the_host_mirror(oracle):
-    """batched getTerrainSig / isOccupancy / isOccupancyXY on the device grid against the host mirror of the
-    reference's lookups (value-only trilinear, posToIndex + isInMap(idx)) -- including out-of-map, seam and border queries"""
+def test_frontend_queries_match_the_oracle_and_the_host_mirror(oracle):
+    """batched getTerrainSig / isOccupancy / isOccupancyXY on the device grid against the ORACLE's lookups (posToIndex +
+    isInMap(idx) on its own occupancy layers, uneven_map.h:389-396, 473-500) and against the product's host mirror -- including out-of-map,
+    seam and border queries, on a grid that HAS occupied cells in both layers"""
     import uneven_planner_amd as U
     from uneven_planner_amd import scenes
     m = U.UnevenMap()
-    m.set_cells(scenes.analytic_cells())
+    cells = scenes.analytic_cells().reshape(200, 200, 64, 4).copy()
+    cells[30:60, 100:140, :, 1] = 0.2                       # sigma > max_rho: occupied in every yaw bin -> both layers
+    cells[120:150, 20:50, 10:20, 2] = 0.7                   # |zb| large in ten yaw bins: c < min_cnormal there -> occ per yaw, occ_r2 for the column
+    m.set_cells(cells.reshape(-1, 4))
     rng = np.random.default_rng(23)
     n = 5000
     pos = np.column_stack([rng.uniform(-5.4, 5.4, n), rng.uniform(-5.4, 5.4, n), rng.uniform(-3.4, 3.4, n)])
     pos[:10] = [[0, 0, -3.095], [0, 0, 3.14159], [4.99995, 0, 0], [-4.99995, -4.99995, 0.3], [5.0, 5.0, 0], [-5.0, 0, 0], [0.0123, 4.97, -3.12],
                 [1, 1, 3.1], [0, 0, 3.17], [0, 0, -3.17]]
+    pos[10:14] = [[-3.0, 1.0, 0.5], [1.5, -3.4, -1.9], [1.5, -3.4, 2.5], [1.7, -3.2, -1.75]]      # inside the two occupied regions
     sg, oc, oxy = m.frontend_query(pos)
     og = oracle.OracleGrid()
     og.set_cells(m.map_buffer)
+    og.compute_occ(min_cnormal=0.8, max_rho=0.05)          # the oracle's OWN occupancy rule (uneven_map.cpp:170-179) on the same cells
+    sg_o, oc_o, oxy_o = og.frontend_query(pos)
+    assert np.array_equal(oc, oc_o) and np.array_equal(oxy, oxy_o)
+    assert np.abs(sg - sg_o).max() < 1e-12
+    assert (oc == 1).sum() > 50 and (oxy == 1).sum() > (oc == 1).sum()      # occupied cells are really exercised, and the xy layer is the OR over yaw
     for i in range(n):
         assert oc[i] == m.isOccupancy(pos[i]) and oxy[i] == m.isOccupancyXY(pos[i])
         assert abs(sg[i] - m.getTerrainSig(pos[i])) < 1e-12
@@ -175,3 +185,32 @@ def test_terrain_pose_query_matches_the_oracle_terrain(oracle, analytic_cells):
     assert np.abs(p[:, 2] - t[:, 0]).max() < 1e-12 and np.array_equal(p[:, :2], pos[:, :2])
     Rh, ph = m.getTerrainPos(pos[7])                               # the host mirror agrees
     assert np.abs(Rh - R[7]).max() < 1e-12 and np.abs(ph - p[7]).max() < 1e-12
+
+
+def test_device_cloud_filter_equals_the_host_form_bit_for_bit():
+    """uph_map_build crops, voxel-filters and buckets the cloud on the device (the host is out of the build).  The cloud it then
+    fits planes to must be the host form's (uph_map_filter_cloud = pcl::CropBox + pcl::VoxelGrid as restated, uneven_map.cpp:133-143) bit for bit --
+    same points, same order -- on the reference's own clouds and on a cloud built to exercise every branch: points outside the box and on its
+    faces, NaN / inf coordinates, many points per 1 cm leaf (float centroids summed in input order), duplicates."""
+    import os
+    import uneven_planner_amd as U
+    from uneven_planner_amd import scenes
+    here = os.path.dirname(os.path.abspath(__file__))
+    rng = np.random.default_rng(3)
+    dense = np.column_stack([rng.uniform(-1.0, 1.0, 60000), rng.uniform(-1.0, 1.0, 60000), 0.3 + 0.02 * rng.standard_normal(60000)]).astype(np.float32)   # ~15 points per leaf column
+    odd = np.array([[10.0, 0, 0], [-10.0, -10.0, -0.01], [10.0, 10.0, 5.0], [10.0001, 0, 0], [0, 0, 5.0001], [0, 0, -0.0101], [np.nan, 0, 0], [0, np.inf, 0],
+                    [0.5, 0.5, 0.3], [0.5, 0.5, 0.3], [0.5, 0.5, 0.3]], dtype=np.float32)
+    tricky = np.concatenate([dense[:30000], odd, dense[30000:], 12.0 * dense[:500]])
+    clouds = [("hill", scenes.make_hill_cloud()), ("tricky", tricky)]
+    for nm in ("desert", "vocano"):
+        clouds.append((nm, np.load(os.path.join(here, "golden", "%s_xyz.npz" % nm))["xyz"]))
+    for nm, xyz in clouds:
+        m = U.UnevenMap()
+        m.build(xyz, x0=100, x1=101, download=False)
+        host = U.UnevenMap.filter_cloud(xyz)
+        dev = m.built_cloud()
+        assert dev.shape == host.shape, (nm, dev.shape, host.shape)
+        assert np.array_equal(dev.view(np.uint32), host.view(np.uint32)), nm
+        st = m.build_stats()
+        assert st["cloud_points"] == len(host) and st["stages_ms"]["call"] > 0
+    assert len(U.UnevenMap.filter_cloud(tricky)) < len(tricky) - 20000          # leaves really merged points

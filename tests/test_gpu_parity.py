@@ -196,8 +196,12 @@ def test_final_trajectories_within_the_optimisers_own_reproducibility(dev, oracl
     assert got["x_median"] <= 3.0 * floor["x_median"] + 1e-6
     assert got["x_p90"] <= 3.0 * floor["x_p90"] + 1e-6
     assert got["c_median"] <= 3.0 * floor["c_median"] + 1e-6
-    assert got["x_le_1e4"] >= floor["x_le_1e4"] - 0.15
-    # a flipped return code is a solve that crosses the 11-pass cap (ret 2) on one side only; the device's evaluation noise
-    # (~1e-13, dense MINCO operator) is larger than an FMA's (~1e-16), so its paths decorrelate a few dozen iterations earlier
-    assert got["same_ret"] >= floor["same_ret"] - 0.25
+    n_ = len(probs)
+    assert got["x_le_1e4"] >= floor["x_le_1e4"] - 2.0 * np.sqrt((got["x_le_1e4"] * (1 - got["x_le_1e4"]) + floor["x_le_1e4"] * (1 - floor["x_le_1e4"])) / n_) - 1e-12
+    # a flipped return code is a solve that crosses the 11-pass cap (ret 2) on one side only.  What is asserted is that the flips are not
+    # ONE-SIDED and not more frequent than the oracle's own against its FMA rebuild, with statistical (2 SE) instead of fixed slack:
+    # converged rate by McNemar's paired difference, same-return-code rate, and a sign test on the final costs (tests/sensitivity.py)
+    st = sensitivity.drift_stats(ref, fma, out)
+    print("drift:", st)
+    sensitivity.assert_no_directional_drift(st, "analytic grid, 48 problems")
     opt.set_rho(1.0)

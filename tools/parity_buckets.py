@@ -48,8 +48,16 @@ def main():
         dev = opt.optimize_batch(probs)
         report[tag] = dict(device=bucket_table(ref, dev), floor=bucket_table(ref, fma),
                            same_ret_device=float(np.mean([a["ret"] == b["ret"] for a, b in zip(dev, ref)])),
-                           same_ret_floor=float(np.mean([a["ret"] == b["ret"] for a, b in zip(fma, ref)])))
+                           same_ret_floor=float(np.mean([a["ret"] == b["ret"] for a, b in zip(fma, ref)])),
+                           drift=sensitivity.drift_stats(ref, fma, dev))
+        dr = report[tag]["drift"]
         print("== %s   (same return code: device %.0f %%, floor %.0f %%)" % (tag, 100 * report[tag]["same_ret_device"], 100 * report[tag]["same_ret_floor"]))
+        print("   converged: oracle %.3f  oracle(FMA) %.3f  device %.3f | discordant device-only %d / oracle-only %d (McNemar p %.2g), FMA-only %d / oracle-only %d (p %.2g)"
+              " | final cost lower / higher than the oracle's: device %d / %d (sign test p %.2g), FMA %d / %d (p %.2g)" % (
+                  dr["converged_frac"]["oracle"], dr["converged_frac"]["oracle_fma"], dr["converged_frac"]["device"], dr["device_vs_oracle"]["device_only"],
+                  dr["device_vs_oracle"]["oracle_only"], dr["device_vs_oracle"]["mcnemar_p"], dr["fma_vs_oracle"]["fma_only"], dr["fma_vs_oracle"]["oracle_only"],
+                  dr["fma_vs_oracle"]["mcnemar_p"], dr["device_vs_oracle"]["cost_lower"], dr["device_vs_oracle"]["cost_higher"], dr["device_vs_oracle"]["cost_sign_p"],
+                  dr["fma_vs_oracle"]["cost_lower"], dr["fma_vs_oracle"]["cost_higher"], dr["fma_vs_oracle"]["cost_sign_p"]))
         print("  L-BFGS iterations    n | device: way-points<=1e-4  cost<=1e-4  median   max    | oracle(FMA): way-points<=1e-4  cost<=1e-4  median   max")
         for d, f in zip(report[tag]["device"], report[tag]["floor"]):
             print("  [%4d, %6d) %5d |        %5.0f %%          %5.0f %%   %.1e %.1e |             %5.0f %%          %5.0f %%   %.1e %.1e" % (

@@ -74,9 +74,16 @@ out = sys.argv[1]
 vals = {}
 for line in open(out + '/pmc_summary.txt'):
     k = line.split(); vals[k[0]] = float(k[1])
-B = int(json.loads(open(out + '/bench.json').read().strip().split('\n')[-1])['config']['batch_per_gpu'])
-import os
+line = json.loads(open(out + '/bench.json').read().strip().split('\n')[-1])
+B = int(line['config']['batch_per_gpu'])
+import os, subprocess
+sys.path.insert(0, os.environ['GRAFT_REPO_ROOT'])
+import bench
+try: head = subprocess.check_output(['git', '-C', os.environ['GRAFT_REPO_ROOT'], 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+except Exception: head = os.environ.get('UPH_GIT_HEAD', 'unknown (the GPU box holds a snapshot without .git)')
 json.dump({'batch': B, 'tag': 'profiles/%s_pmc_summary.txt' % os.path.basename(out).replace('prof_', ''), 'fetch_kib': vals.get('FETCH_SIZE', 0.0), 'write_kib': vals.get('WRITE_SIZE', 0.0), 'launches': 1,
+           'sq_active_inst_valu': vals.get('SQ_ACTIVE_INST_VALU', 0.0), 'sq_wave_cycles': vals.get('SQ_WAVE_CYCLES', 0.0), 'sq_wait_any': vals.get('SQ_WAIT_ANY', 0.0), 'sq_insts_valu': vals.get('SQ_INSTS_VALU', 0.0),
+           'launch_ms': line['roofline']['avg_launch_ms'], 'kernel_src_sha': bench.kernel_sources_sha(), 'git_head': head,
            'note': 'ALM/L-BFGS solve kernel (uph_solver_kernel<*,2,2>), one launch of bench.py --steps 1 --warmup 0 (default batch); rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; see <tag>_fetch_calibration.txt for counted/requested on known patterns'},
           open(out + '/pmc_traffic.json', 'w'), indent=1)
 PY

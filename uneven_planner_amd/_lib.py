@@ -35,6 +35,13 @@ class FbmParams(C.Structure):
                 ("rough_lambda", C.c_double), ("patch_lambda", C.c_double), ("rough_threshold", C.c_double)]
 
 
+class KinoParams(C.Structure):
+    _fields_ = [("yaw_resolution", C.c_double), ("lambda_heu", C.c_double), ("weight_r2", C.c_double), ("weight_so2", C.c_double),
+                ("weight_v_change", C.c_double), ("weight_delta_change", C.c_double), ("weight_sigma", C.c_double), ("time_interval", C.c_double),
+                ("collision_interval", C.c_double), ("oneshot_range", C.c_double), ("wheel_base", C.c_double), ("max_steer", C.c_double),
+                ("max_vel", C.c_double)]
+
+
 FBM_MAX_WAVES = 48
 FBM_TABLE_DOUBLES = 4 * FBM_MAX_WAVES + 12 + 9
 DP = C.POINTER(C.c_double)
@@ -82,6 +89,7 @@ SYMBOLS = {
     "uph_rccl_selftest": (C.c_int, [_I32, C.c_char_p, _I32]),
     "uph_optimize_batch_multi": (C.c_int, [C.POINTER(_VP), _I32, _I32, C.POINTER(Problem), C.POINTER(Result)]),
     "uph_batch_count": (C.c_int, [_VP]),
+    "uph_batch_origin": (C.c_int, [_VP, C.POINTER(_I32)]),
     "uph_map_cells_device": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I64)]),
     "uph_map_commit": (C.c_int, [_VP]),
     "uph_map_export_slab_dev": (C.c_int, [_VP, _I32, _I32, _VP]),
@@ -92,6 +100,8 @@ SYMBOLS = {
     "uph_frontend_query_ms": (C.c_int, [_VP, DP]),
     "uph_map_filter_cloud": (_I64, [C.POINTER(C.c_float), _I64, C.POINTER(C.c_float), _I64]),
     "uph_map_build_stats": (C.c_int, [_VP, DP, C.POINTER(_I64), C.POINTER(_I64)]),
+    "uph_map_build_stages": (C.c_int, [_VP, DP]),
+    "uph_map_built_cloud": (_I64, [_VP, C.POINTER(C.c_float), _I64]),
     "uph_ctx_create": (C.c_int, [_VP, C.POINTER(OptParams), C.POINTER(_VP)]),
     "uph_ctx_destroy": (None, [_VP]),
     "uph_ctx_set_lanes": (C.c_int, [_VP, _I32]),
@@ -120,6 +130,12 @@ SYMBOLS = {
     "uph_batch_set_lbfgs_state": (C.c_int, [_VP, DP, DP, DP, DP, DP, DP, DP]),
     "uph_batch_lbfgs_resume": (C.c_int, [_VP, _I32, _I32]),
     "uph_batch_get_lbfgs_state": (C.c_int, [_VP, DP, DP, DP, DP, DP, DP, DP]),
+    "uph_kino_create": (C.c_int, [_VP, C.POINTER(KinoParams), _I32, C.POINTER(_VP)]),
+    "uph_kino_destroy": (None, [_VP]),
+    "uph_kino_slots": (C.c_int, [_VP]),
+    "uph_kino_primitives": (C.c_int, [_VP]),
+    "uph_kino_plan_batch": (C.c_int, [_VP, _I32, DP, DP, _I32, DP, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), _I32, _I32, C.POINTER(_I32)]),
+    "uph_kino_stats": (C.c_int, [_VP, DP]),
 }
 
 _LIB = None

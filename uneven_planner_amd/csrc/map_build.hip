@@ -15,6 +15,7 @@
 // literally, followed by the reference's fp64 ellipsoid test (:366-377).  The 3x3 covariance eigen-problem
 // (Eigen::EigenSolver in the reference) is solved with cyclic Jacobi in registers.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -48,6 +49,12 @@ struct uph_map {
     size_t scratch_cap[4] = {0, 0, 0, 0};
     double last_build_ms = 0.0, last_query_ms = 0.0;
     int64_t last_cell_iters = 0, last_cloud = 0;
+    // build scratch (grow-only, reused by every build: no allocation per call once warm) and the events of the kernel timing
+    void* bscr[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t bscr_cap[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t bev0 = nullptr, bev1 = nullptr;
+    double stage_ms[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // last build: cloud upload, crop + voxel filter, bucketing, plane-fit kernel (HIP events), commit, total wall
+    int64_t last_raw = 0;
     double multi_ms[4] = {0.0, 0.0, 0.0, 0.0};      // last uph_map_*_multi led by this map: slab fits (wall), slab exchange (wall), commit (wall), exchange (HIP events, device 0)
     int multi_rccl = 0;                             // ... and whether the exchange went through RCCL (1) or device-to-device copies (0)
 };
@@ -66,6 +73,7 @@ void* uphMapScratch(uph_map* m, int slot, size_t bytes) {
     return m->scratch[slot];
 }
 GridDev uphMapGrid(const uph_map* m) { return m->g; }
+void uphMapOcc(const uph_map* m, const char** occ, const char** occ_r2) { *occ = m->d_occ; *occ_r2 = m->d_occ2; }
 
 #define HIPCHK(call)                                                                               \
     do {                                                                                           \
@@ -408,6 +416,99 @@ __global__ void uph_window_kernel(int ny, int nyaw, const double* __restrict__ c
     out[i] = cells32 ? (double)cells32[a] : cells[a];
 }
 
+
+// ------------------------------------------------------------------------------------------------ cloud preparation on the device
+// UnevenMap::init's pcl::CropBox + pcl::VoxelGrid (uneven_map.cpp:133-143) and the xy bucketing of the plane-fit kernel's input, without the
+// host: the same float predicates and integer keys as cropAndVoxel() below (which stays as the host form behind uph_map_filter_cloud and as
+// the checker of this path: tests/test_gpu_map.py compares the two bit for bit), stable radix sorts (hipcub) for "ordered by leaf index" /
+// "ordered by bucket", sequential float sums per leaf in input order.
+__device__ __forceinline__ unsigned fOrd(float f) { const unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }      // order-preserving float -> uint
+__host__ __device__ inline float fOrdInv(unsigned u) { const unsigned b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &b, 4); return f; }
+
+__global__ void uph_crop_flag_kernel(const float* __restrict__ xyz, int n, int* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
+    const bool fin = isfinite(px) && isfinite(py) && isfinite(pz);
+    flag[i] = (fin && !(px < -10.0f || py < -10.0f || pz < -0.01f || px > 10.0f || py > 10.0f || pz > 5.0f)) ? 1 : 0;
+}
+__global__ void uph_compact_kernel(const float* __restrict__ xyz, int n, const int* __restrict__ flag, const int* __restrict__ pos, float* __restrict__ cx, float* __restrict__ cy,
+                                   float* __restrict__ cz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const int o = pos[i];
+    cx[o] = xyz[3 * (size_t)i]; cy[o] = xyz[3 * (size_t)i + 1]; cz[o] = xyz[3 * (size_t)i + 2];
+}
+// mm[0..2] = min of x, y, z; mm[3..5] = max (order-preserving uint encoding; initialised to 0xffffffff / 0)
+__global__ void uph_minmax3_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n, unsigned* __restrict__ mm) {
+    unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned a = fOrd(x[i]), b = fOrd(y[i]), c = fOrd(z[i]);
+        lo[0] = min(lo[0], a); hi[0] = max(hi[0], a); lo[1] = min(lo[1], b); hi[1] = max(hi[1], b); lo[2] = min(lo[2], c); hi[2] = max(hi[2], c);
+    }
+    for (int k = 0; k < 3; k++) {
+        for (int off = 32; off >= 1; off >>= 1) { lo[k] = min(lo[k], (unsigned)__shfl_xor((int)lo[k], off)); hi[k] = max(hi[k], (unsigned)__shfl_xor((int)hi[k], off)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&mm[k], lo[k]); atomicMax(&mm[3 + k], hi[k]); }
+    }
+}
+// leaf key of pcl::VoxelGrid: ijk = floor(coord * inv_leaf) - min_b in float, key = i + j * div0 + k * div0 * div1
+__global__ void uph_voxel_key_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n, float inv, float mb0, float mb1, float mb2, int mul1,
+                                     int mul2, int* __restrict__ key, int* __restrict__ idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int i0 = (int)(floorf(x[i] * inv) - mb0), i1 = (int)(floorf(y[i] * inv) - mb1), i2 = (int)(floorf(z[i] * inv) - mb2);
+    key[i] = i0 + i1 * mul1 + i2 * mul2;
+    idx[i] = i;
+}
+__global__ void uph_head_kernel(const int* __restrict__ skey, int n, int* __restrict__ head) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || skey[i] != skey[i - 1]) ? 1 : 0;
+}
+// one thread per leaf: float centroid of its points, summed in input order (the sort is stable)
+__global__ void uph_centroid_kernel(const int* __restrict__ skey, const int* __restrict__ sidx, const int* __restrict__ head, const int* __restrict__ vid, int n, const float* __restrict__ x,
+                                    const float* __restrict__ y, const float* __restrict__ z, float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int t = i;
+    for (; t < n && skey[t] == skey[i]; t++) { const int q = sidx[t]; sx += x[q]; sy += y[q]; sz += z[q]; }
+    const float cnt = (float)(t - i);
+    const int o = vid[i];
+    ox[o] = sx / cnt; oy[o] = sy / cnt; oz[o] = sz / cnt;
+}
+__global__ void uph_bucket_key_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, float bx0, float by0, float bsize, int bnx, int bny, int* __restrict__ key,
+                                      int* __restrict__ idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ix = min(bnx - 1, (int)((x[i] - bx0) / bsize)), iy = min(bny - 1, (int)((y[i] - by0) / bsize));
+    key[i] = ix * bny + iy;
+    idx[i] = i;
+}
+__global__ void uph_pack_pts_kernel(const int* __restrict__ sidx, int n, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, float4* __restrict__ pts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int q = sidx[i];
+    pts[i] = make_float4(x[q], y[q], z[q], __int_as_float(q));
+}
+// bstart[b] = first sorted position whose bucket key is >= b (b = 0 .. nb)
+__global__ void uph_bstart_kernel(const int* __restrict__ skey, int n, int nb, int* __restrict__ bstart) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (skey[mid] < b) lo = mid + 1; else hi = mid; }
+    bstart[b] = lo;
+}
+// largest point count of any (2 hw + 1)^2 bucket window: the LDS capacity of the plane-fit kernel's staging area
+__global__ void uph_cap_kernel(const int* __restrict__ bstart, int bnx, int bny, int hw, int* __restrict__ cap) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= bnx * bny) return;
+    const int ix = b / bny, iy = b % bny;
+    const int xa = max(0, ix - hw), xb = min(bnx, ix + hw + 1), ya = max(0, iy - hw), yb = min(bny, iy + hw + 1);
+    int cnt = 0;
+    for (int r = xa; r < xb; r++) cnt += bstart[r * bny + yb] - bstart[r * bny + ya];
+    atomicMax(cap, cnt);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 
@@ -576,6 +677,9 @@ void uph_map_destroy(uph_map* m) {
     hipSetDevice(m->device);
     hipFree(m->d_cells); hipFree(m->d_cells32); hipFree(m->d_c); hipFree(m->d_occ); hipFree(m->d_occ2);
     for (int k = 0; k < 4; k++) hipFree(m->scratch[k]);
+    for (int k = 0; k < 16; k++) hipFree(m->bscr[k]);
+    if (m->bev0) hipEventDestroy(m->bev0);
+    if (m->bev1) hipEventDestroy(m->bev1);
     delete m;
 }
 
@@ -765,81 +869,162 @@ int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x
 static int buildSlab(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x1, bool commit) {
     if (m && m->d_cells32) { setError("uph_map_build: the plane fit writes fp64 cells; create the map with uph_map_create"); return UPH_ERR_INVALID; }
     if (!m || !xyz || n <= 0) { setError("uph_map_build: bad arguments"); return UPH_ERR_INVALID; }
+    if (n > (int64_t)INT32_MAX) { setError("uph_map_build: more than 2^31 points"); return UPH_ERR_LIMIT; }
     const GridDev& g = m->g;
     if (x0 < g.x_off || x1 > g.x_off + g.nx_hold || x0 >= x1) { setError("uph_map_build: bad x-slab"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
-    HostCloud cl = cropAndVoxel(xyz, n);
-    const size_t np = cl.size();
-    if (np == 0) { setError("uph_map_build: no points inside the crop box"); return UPH_ERR_INVALID; }
-    // xy buckets of 0.16 m: a query disc of 0.32 m around a cell centre touches at most 5 x 5 buckets
-    const float bsize = 0.16f;
-    float bx0 = cl.x[0], by0 = cl.y[0], bx1 = cl.x[0], by1 = cl.y[0];
-    for (size_t i = 0; i < np; i++) { bx0 = std::min(bx0, cl.x[i]); bx1 = std::max(bx1, cl.x[i]); by0 = std::min(by0, cl.y[i]); by1 = std::max(by1, cl.y[i]); }
-    const int bnx = (int)((bx1 - bx0) / bsize) + 1, bny = (int)((by1 - by0) / bsize) + 1;
-    std::vector<int> bstart((size_t)bnx * bny + 1, 0);
-    auto bucketOf = [&](size_t i) { const int ix = std::min(bnx - 1, (int)((cl.x[i] - bx0) / bsize)), iy = std::min(bny - 1, (int)((cl.y[i] - by0) / bsize)); return ix * bny + iy; };
-    for (size_t i = 0; i < np; i++) bstart[bucketOf(i) + 1]++;
-    for (size_t b = 1; b < bstart.size(); b++) bstart[b] += bstart[b - 1];
-    std::vector<float4> pts(np);
-    {
-        std::vector<int> cur(bstart.begin(), bstart.end() - 1);
-        for (size_t i = 0; i < np; i++) {
-            float4 p; p.x = cl.x[i]; p.y = cl.y[i]; p.z = cl.z[i];
-            const int idx = (int)i;
-            std::memcpy(&p.w, &idx, 4);
-            pts[cur[bucketOf(i)]++] = p;
-        }
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_mark = t_begin;
+    auto lap = [&]() { const auto now = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(now - t_mark).count(); t_mark = now; return ms; };
+    // grow-only scratch of the map handle: slot -> bytes
+    auto scr = [&](int slot, size_t bytes) -> void* {
+        if (bytes <= m->bscr_cap[slot]) return m->bscr[slot];
+        if (m->bscr[slot]) hipFree(m->bscr[slot]);
+        m->bscr[slot] = nullptr; m->bscr_cap[slot] = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&m->bscr[slot], want) != hipSuccess) { setError("uph_map_build: hipMalloc of build scratch failed"); return nullptr; }
+        m->bscr_cap[slot] = want;
+        return m->bscr[slot];
+    };
+    const int N = (int)n;
+    const unsigned nb_ = (unsigned)((N + 255) / 256);
+    // slots: 0 raw xyz | 1 flag / head | 2 scan | 3,4,5 cropped x y z | 6 key | 7 idx | 8 sorted key | 9 sorted idx | 10,11,12 filtered x y z | 13 pts + bstart | 14 cub temp | 15 small
+    float* d_raw = (float*)scr(0, sizeof(float) * 3 * (size_t)N);
+    int* d_flag = (int*)scr(1, sizeof(int) * (size_t)N);
+    int* d_scan = (int*)scr(2, sizeof(int) * (size_t)N);
+    float *d_cx = (float*)scr(3, 4 * (size_t)N), *d_cy = (float*)scr(4, 4 * (size_t)N), *d_cz = (float*)scr(5, 4 * (size_t)N);
+    int *d_key = (int*)scr(6, 4 * (size_t)N), *d_idx = (int*)scr(7, 4 * (size_t)N), *d_skey = (int*)scr(8, 4 * (size_t)N), *d_sidx = (int*)scr(9, 4 * (size_t)N);
+    float *d_fx = (float*)scr(10, 4 * (size_t)N), *d_fy = (float*)scr(11, 4 * (size_t)N), *d_fz = (float*)scr(12, 4 * (size_t)N);
+    unsigned* d_small = (unsigned*)scr(15, 64);
+    if (!d_raw || !d_flag || !d_scan || !d_cx || !d_cy || !d_cz || !d_key || !d_idx || !d_skey || !d_sidx || !d_fx || !d_fy || !d_fz || !d_small) return UPH_ERR_HIP;
+    size_t tb_scan = 0, tb_sort = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tb_scan, d_flag, d_scan, N, 0);
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tb_sort, d_key, d_skey, d_idx, d_sidx, N, 0, 32, 0);
+    size_t tb = std::max(tb_scan, tb_sort);
+    void* d_tmp = scr(14, tb);
+    if (!d_tmp) return UPH_ERR_HIP;
+    HIPCHK(hipMemcpy(d_raw, xyz, sizeof(float) * 3 * (size_t)N, hipMemcpyHostToDevice));
+    m->stage_ms[0] = lap();
+    // ---- pcl::CropBox (:133-137): inclusive float box, finite points, order kept
+    hipLaunchKernelGGL(uph_crop_flag_kernel, dim3(nb_), dim3(256), 0, 0, d_raw, N, d_flag);
+    hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_flag, d_scan, N, 0);
+    hipLaunchKernelGGL(uph_compact_kernel, dim3(nb_), dim3(256), 0, 0, d_raw, N, d_flag, d_scan, d_cx, d_cy, d_cz);
+    int last_flag = 0, last_pos = 0;
+    HIPCHK(hipMemcpy(&last_flag, d_flag + (N - 1), 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&last_pos, d_scan + (N - 1), 4, hipMemcpyDeviceToHost));
+    const int nc = last_pos + last_flag;                       // points inside the crop box
+    if (nc == 0) { setError("uph_map_build: no points inside the crop box"); return UPH_ERR_INVALID; }
+    // ---- pcl::VoxelGrid, 1 cm leaf (:139-143): extent -> min_b / div_b on the host (six floats cross), keys + stable sort + per-leaf centroid on the device
+    unsigned mm[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    HIPCHK(hipMemcpy(d_small, mm, sizeof(mm), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(uph_minmax3_kernel, dim3(std::min(1024, (nc + 255) / 256)), dim3(256), 0, 0, d_cx, d_cy, d_cz, nc, d_small);
+    HIPCHK(hipMemcpy(mm, d_small, sizeof(mm), hipMemcpyDeviceToHost));
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) { lo[k] = fOrdInv(mm[k]); hi[k] = fOrdInv(mm[3 + k]); }
+    const float inv = 1.0f / 0.01f;
+    const int64_t dx = (int64_t)((hi[0] - lo[0]) * inv) + 1, dy = (int64_t)((hi[1] - lo[1]) * inv) + 1, dz = (int64_t)((hi[2] - lo[2]) * inv) + 1;
+    int np = 0;
+    const float *fx = d_cx, *fy = d_cy, *fz = d_cz;            // the filtered cloud (device)
+    if (dx * dy * dz > (int64_t)INT32_MAX) {
+        np = nc;                                               // PCL: leaf too small for the extent -> the cropped cloud passes through unfiltered
+    } else {
+        int minb[3], divb[3];
+        for (int k = 0; k < 3; k++) { minb[k] = (int)std::floor(lo[k] * inv); divb[k] = (int)std::floor(hi[k] * inv) - minb[k] + 1; }
+        const unsigned nbc = (unsigned)((nc + 255) / 256);
+        hipLaunchKernelGGL(uph_voxel_key_kernel, dim3(nbc), dim3(256), 0, 0, d_cx, d_cy, d_cz, nc, inv, (float)minb[0], (float)minb[1], (float)minb[2], divb[0], divb[0] * divb[1], d_key, d_idx);
+        hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_key, d_skey, d_idx, d_sidx, nc, 0, 32, 0);
+        hipLaunchKernelGGL(uph_head_kernel, dim3(nbc), dim3(256), 0, 0, d_skey, nc, d_flag);
+        hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_flag, d_scan, nc, 0);
+        hipLaunchKernelGGL(uph_centroid_kernel, dim3(nbc), dim3(256), 0, 0, d_skey, d_sidx, d_flag, d_scan, nc, d_cx, d_cy, d_cz, d_fx, d_fy, d_fz);
+        HIPCHK(hipMemcpy(&last_flag, d_flag + (nc - 1), 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&last_pos, d_scan + (nc - 1), 4, hipMemcpyDeviceToHost));
+        np = last_pos + last_flag;
+        fx = d_fx; fy = d_fy; fz = d_fz;
     }
+    HIPCHK(hipGetLastError());
+    m->stage_ms[1] = lap();
+    // ---- xy buckets of 0.16 m: a query disc of 0.32 m around a cell centre touches at most 5 x 5 buckets
+    const float bsize = 0.16f;
+    unsigned mm2[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    HIPCHK(hipMemcpy(d_small, mm2, sizeof(mm2), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(uph_minmax3_kernel, dim3(std::min(1024, (np + 255) / 256)), dim3(256), 0, 0, fx, fy, fz, np, d_small);
+    HIPCHK(hipMemcpy(mm2, d_small, sizeof(mm2), hipMemcpyDeviceToHost));
+    const float bx0 = fOrdInv(mm2[0]), by0 = fOrdInv(mm2[1]), bx1 = fOrdInv(mm2[3]), by1 = fOrdInv(mm2[4]);
+    const int bnx = (int)((bx1 - bx0) / bsize) + 1, bny = (int)((by1 - by0) / bsize) + 1;
+    const size_t nbuck = (size_t)bnx * bny;
+    char* d_pb = (char*)scr(13, sizeof(float4) * (size_t)np + sizeof(int) * (nbuck + 1) + 64);
+    if (!d_pb) return UPH_ERR_HIP;
+    float4* d_pts = (float4*)d_pb;
+    int* d_bstart = (int*)(d_pb + sizeof(float4) * (size_t)np);
+    const unsigned nbp = (unsigned)((np + 255) / 256);
+    hipLaunchKernelGGL(uph_bucket_key_kernel, dim3(nbp), dim3(256), 0, 0, fx, fy, np, bx0, by0, bsize, bnx, bny, d_key, d_idx);
+    int key_bits = 1;
+    while (((size_t)1 << key_bits) < nbuck + 1 && key_bits < 31) key_bits++;
+    hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_key, d_skey, d_idx, d_sidx, np, 0, key_bits, 0);      // stable: filtered-cloud order inside a bucket
+    hipLaunchKernelGGL(uph_pack_pts_kernel, dim3(nbp), dim3(256), 0, 0, d_sidx, np, fx, fy, fz, d_pts);
+    hipLaunchKernelGGL(uph_bstart_kernel, dim3((unsigned)((nbuck + 1 + 255) / 256)), dim3(256), 0, 0, d_skey, np, (int)nbuck, d_bstart);
     // LDS capacity: the largest point count of any (2 hw + 1)^2 bucket window, hw from the staging radius the kernel uses
     // (0.12 probe offset + largest ellipsoid axis + margin): covers every staged disc for whatever ellipsoid the parameters give
     const double box_r = std::max(std::max(m->mp.ellipsoid_x, m->mp.ellipsoid_y), m->mp.ellipsoid_z);
     const int hw = (int)std::ceil((0.12 + box_r + 1.0e-3) / bsize) + 1;
     int cap = 64;
-    {
-        std::vector<int64_t> ps((size_t)(bnx + 1) * (bny + 1), 0);
-        for (int ix = 0; ix < bnx; ix++)
-            for (int iy = 0; iy < bny; iy++) {
-                const int cnt = bstart[ix * bny + iy + 1] - bstart[ix * bny + iy];
-                ps[(size_t)(ix + 1) * (bny + 1) + iy + 1] = cnt + ps[(size_t)ix * (bny + 1) + iy + 1] + ps[(size_t)(ix + 1) * (bny + 1) + iy] - ps[(size_t)ix * (bny + 1) + iy];
-            }
-        for (int ix = 0; ix < bnx; ix++)
-            for (int iy = 0; iy < bny; iy++) {
-                const int xa = std::max(0, ix - hw), xb = std::min(bnx, ix + hw + 1), ya = std::max(0, iy - hw), yb = std::min(bny, iy + hw + 1);
-                const int64_t cnt = ps[(size_t)xb * (bny + 1) + yb] - ps[(size_t)xa * (bny + 1) + yb] - ps[(size_t)xb * (bny + 1) + ya] + ps[(size_t)xa * (bny + 1) + ya];
-                cap = std::max<int64_t>(cap, cnt);
-            }
-    }
+    HIPCHK(hipMemcpy(d_small + 8, &cap, 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(uph_cap_kernel, dim3((unsigned)((nbuck + 255) / 256)), dim3(256), 0, 0, d_bstart, bnx, bny, hw, (int*)(d_small + 8));
+    int ovf0 = 0;
+    HIPCHK(hipMemcpy(d_small + 9, &ovf0, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(&cap, d_small + 8, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipGetLastError());
+    m->stage_ms[2] = lap();
     const size_t lds_bytes = (size_t)cap * sizeof(float4);
     if (lds_bytes > 150 * 1024) { setError("uph_map_build: cloud too dense for the LDS staging window"); return UPH_ERR_LIMIT; }
-    UphDevTmp t_pts, t_bstart, t_ovf;
-    HIPCHK(hipMalloc(&t_pts.p, np * sizeof(float4)));
-    HIPCHK(hipMalloc(&t_bstart.p, bstart.size() * sizeof(int)));
-    HIPCHK(hipMalloc(&t_ovf.p, sizeof(int)));
-    HIPCHK(hipMemset(t_ovf.p, 0, sizeof(int)));
-    HIPCHK(hipMemcpy(t_pts.p, pts.data(), np * sizeof(float4), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(t_bstart.p, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice));
     CloudDev cd;
-    cd.pts = t_pts.as<float4>(); cd.bstart = t_bstart.as<int>(); cd.bx0 = bx0; cd.by0 = by0; cd.bsize = bsize; cd.bnx = bnx; cd.bny = bny; cd.npts = (int)np;
+    cd.pts = d_pts; cd.bstart = d_bstart; cd.bx0 = bx0; cd.by0 = by0; cd.bsize = bsize; cd.bnx = bnx; cd.bny = bny; cd.npts = np;
     HIPCHK(hipFuncSetAttribute((const void*)uph_map_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    UphEventTmp e0, e1;
-    HIPCHK(hipEventCreate((hipEvent_t*)&e0.e));
-    HIPCHK(hipEventCreate((hipEvent_t*)&e1.e));
+    if (!m->bev0) { HIPCHK(hipEventCreate(&m->bev0)); HIPCHK(hipEventCreate(&m->bev1)); }
     const int ncol = (x1 - x0) * g.ny;
-    HIPCHK(hipEventRecord((hipEvent_t)e0.e, 0));
+    HIPCHK(hipEventRecord(m->bev0, 0));
     hipLaunchKernelGGL(uph_map_build_kernel, dim3(ncol), dim3(64), lds_bytes, 0, g, cd, m->d_cells, (int)x0, (int)x1, (int)m->mp.iter_num, m->mp.ellipsoid_x,
-                       m->mp.ellipsoid_y, m->mp.ellipsoid_z, cap, t_ovf.as<int>());
+                       m->mp.ellipsoid_y, m->mp.ellipsoid_z, cap, (int*)(d_small + 9));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord((hipEvent_t)e1.e, 0));
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(m->bev1, 0));
     int ovf = 0;
-    HIPCHK(hipMemcpy(&ovf, t_ovf.p, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&ovf, d_small + 9, sizeof(int), hipMemcpyDeviceToHost));      // (synchronises with the kernel)
     if (ovf) { setError("uph_map_build: a staged neighbourhood exceeded the LDS window (internal sizing error)"); return UPH_ERR_LIMIT; }
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)e0.e, (hipEvent_t)e1.e));
+    HIPCHK(hipEventElapsedTime(&ms, m->bev0, m->bev1));
     m->last_build_ms = ms;
+    m->stage_ms[3] = ms; (void)lap();
     m->last_cell_iters = (int64_t)ncol * g.nyaw * m->mp.iter_num;
     m->last_cloud = (int64_t)np;
-    return commit ? commitMap(m) : UPH_OK;
+    m->last_raw = n;
+    const int rc = commit ? commitMap(m) : UPH_OK;
+    m->stage_ms[4] = lap();
+    m->stage_ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return rc;
+}
+
+// stages of the last uph_map_build on this map, milliseconds: [0] cloud upload, [1] crop box + voxel filter (device), [2] bucketing + LDS sizing (device),
+// [3] plane-fit kernel (HIP events), [4] commit (c, occupancy), [5] the whole call (wall)
+int uph_map_build_stages(uph_map* m, double* out6) {
+    if (!m || !out6) return UPH_ERR_INVALID;
+    for (int k = 0; k < 6; k++) out6[k] = m->stage_ms[k];
+    return UPH_OK;
+}
+// the cloud the last uph_map_build fitted planes to, as the device filtered it (crop box + voxel grid): at most cap points into out_xyz, returns
+// the count.  Diagnostic / test hook: must equal uph_map_filter_cloud (the host form) bit for bit.
+int64_t uph_map_built_cloud(uph_map* m, float* out_xyz, int64_t cap) {
+    if (!m || m->last_cloud <= 0 || !m->bscr[13]) { setError("uph_map_built_cloud: no build on this map"); return UPH_ERR_INVALID; }
+    if (hipSetDevice(m->device) != hipSuccess) return UPH_ERR_HIP;
+    const int64_t np = m->last_cloud;
+    if (out_xyz) {
+        std::vector<float4> pts((size_t)np);
+        if (hipMemcpy(pts.data(), m->bscr[13], sizeof(float4) * (size_t)np, hipMemcpyDeviceToHost) != hipSuccess) { setError("uph_map_built_cloud: hipMemcpy failed"); return UPH_ERR_HIP; }
+        for (const float4& p : pts) {                         // bucket order -> filtered-cloud order through the index carried in .w
+            int idx; std::memcpy(&idx, &p.w, 4);
+            if (idx >= 0 && idx < cap) { out_xyz[3 * (size_t)idx] = p.x; out_xyz[3 * (size_t)idx + 1] = p.y; out_xyz[3 * (size_t)idx + 2] = p.z; }
+        }
+    }
+    return np;
 }
 
 
@@ -896,11 +1081,23 @@ int checkMultiMaps(uph_map* const* maps, int n, const char* who, bool need_f64) 
         for (int h = 0; h < g; h++) if (maps[h] == m) { setError(std::string(who) + ": the same map twice"); return UPH_ERR_INVALID; }
         if (m->g.nx_hold != m->g.nx) { setError(std::string(who) + ": tile maps hold their own rows only (nothing to gather)"); return UPH_ERR_INVALID; }
         if (need_f64 && m->d_cells32) { setError(std::string(who) + ": the plane fit writes fp64 cells; create the maps with uph_map_create"); return UPH_ERR_INVALID; }
-        if (m->g.nx != maps[0]->g.nx || m->g.ny != maps[0]->g.ny || m->g.nyaw != maps[0]->g.nyaw || (m->d_cells32 != nullptr) != (maps[0]->d_cells32 != nullptr) ||
-            std::memcmp(&m->mp, &maps[0]->mp, sizeof(uph_map_params)) != 0) { setError(std::string(who) + ": the maps differ in parameters or storage"); return UPH_ERR_INVALID; }
+        const uph_map_params &a = m->mp, &b = maps[0]->mp;          // field by field: the struct has padding after iter_num, memcmp would compare it
+        const bool same = a.iter_num == b.iter_num && a.map_size_x == b.map_size_x && a.map_size_y == b.map_size_y && a.ellipsoid_x == b.ellipsoid_x &&
+                          a.ellipsoid_y == b.ellipsoid_y && a.ellipsoid_z == b.ellipsoid_z && a.xy_resolution == b.xy_resolution && a.yaw_resolution == b.yaw_resolution &&
+                          a.min_cnormal == b.min_cnormal && a.max_rho == b.max_rho && a.gravity == b.gravity;
+        if (m->g.nx != maps[0]->g.nx || m->g.ny != maps[0]->g.ny || m->g.nyaw != maps[0]->g.nyaw || (m->d_cells32 != nullptr) != (maps[0]->d_cells32 != nullptr) || !same) {
+            setError(std::string(who) + ": the maps differ in parameters or storage"); return UPH_ERR_INVALID;
+        }
     }
     return UPH_OK;
 }
+
+// the *_multi entry points visit every device; the caller's current HIP device is left as it was found (a PyTorch host relies on it)
+struct DeviceRestore {
+    int dev = -1;
+    DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
 
 double wallMs(std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); }
 
@@ -1023,6 +1220,7 @@ int multiBuild(uph_map* const* maps, int n, const char* who, Fit fit) {
 extern "C" {
 
 int uph_map_build_multi(uph_map* const* maps, int32_t n_gpus, const float* xyz, int64_t n) {
+    DeviceRestore keep;
     int r = checkMultiMaps(maps, n_gpus, "uph_map_build_multi", true);
     if (r != UPH_OK) return r;
     if (!xyz || n <= 0) { setError("uph_map_build_multi: bad arguments"); return UPH_ERR_INVALID; }
@@ -1030,6 +1228,7 @@ int uph_map_build_multi(uph_map* const* maps, int32_t n_gpus, const float* xyz, 
 }
 
 int uph_map_fill_fbm_multi(uph_map* const* maps, int32_t n_gpus, const uph_fbm_params* fp) {
+    DeviceRestore keep;
     int r = checkMultiMaps(maps, n_gpus, "uph_map_fill_fbm_multi", false);
     if (r != UPH_OK) return r;
     if (!checkFbm(fp)) { setError("uph_map_fill_fbm_multi: bad arguments"); return UPH_ERR_INVALID; }
@@ -1049,6 +1248,7 @@ int uph_map_multi_stats(uph_map* lead, double* fit_ms, double* exchange_ms, doub
 // diagnostic: binds RCCL as the sharded build would, forms the clique of devices 0 .. n_devices-1 and all-gathers a known pattern (out of
 // place, 4096 doubles per device).  0 = every device received every block; the bound library and RCCL version go to `info`.
 int uph_rccl_selftest(int32_t n_devices, char* info, int32_t info_cap) {
+    DeviceRestore keep;
     int have = 0;
     if (n_devices < 1 || hipGetDeviceCount(&have) != hipSuccess || have < n_devices) { setError("uph_rccl_selftest: not that many devices"); return UPH_ERR_INVALID; }
     std::string why;
@@ -1090,6 +1290,7 @@ int uph_rccl_selftest(int32_t n_devices, char* info, int32_t info_cap) {
 }
 
 void uph_multi_shutdown(void) {
+    DeviceRestore keep;
     std::lock_guard<std::mutex> lk(g_clique_mu);
     std::string why;
     const RcclApi* api = rcclApi(why);

@@ -187,8 +187,8 @@ class UnevenMap:
         return self
 
     def build(self, xyz, x0=0, x1=None, download=True):
-        """UnevenMap::constructMap (uneven_map.cpp:317-417) on x-slab [x0, x1) -- crop box + 1 cm voxel filter on the host
-        (uneven_map.cpp:133-143), plane fits on the device."""
+        """UnevenMap::constructMap (uneven_map.cpp:317-417) on x-slab [x0, x1) -- crop box + 1 cm voxel filter (uneven_map.cpp:133-143),
+        xy bucketing and plane fits on the device."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         if x1 is None:
             x1 = int(self.voxel_num[0])
@@ -215,7 +215,20 @@ class UnevenMap:
     def build_stats(self):
         ms, ci, cp = C.c_double(0), C.c_int64(0), C.c_int64(0)
         _lib.check(self.L.uph_map_build_stats(self.h, C.byref(ms), C.byref(ci), C.byref(cp)), "uph_map_build_stats")
-        return dict(kernel_ms=ms.value, cell_iters=ci.value, cloud_points=cp.value)
+        st = np.zeros(6)
+        _lib.check(self.L.uph_map_build_stages(self.h, _dp(st)), "uph_map_build_stages")
+        return dict(kernel_ms=ms.value, cell_iters=ci.value, cloud_points=cp.value,
+                    stages_ms=dict(upload=st[0], crop_voxel=st[1], bucket=st[2], kernel=st[3], commit=st[4], call=st[5]))
+
+    def built_cloud(self):
+        """the cloud the last build fitted planes to, as the device filtered it (test hook: equals filter_cloud(xyz) bit for bit)"""
+        fp = C.POINTER(C.c_float)
+        n = self.L.uph_map_built_cloud(self.h, None, 0)
+        if n < 0:
+            _lib.check(int(n), "uph_map_built_cloud")
+        out = np.zeros((int(n), 3), dtype=np.float32)
+        self.L.uph_map_built_cloud(self.h, out.ctypes.data_as(fp), int(n))
+        return out
 
     def set_cells(self, rxs2):
         """Fill the grid from host cells (ncell x 4: z, sigma, zb.x, zb.y in the reference's address order)."""
