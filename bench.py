@@ -160,9 +160,13 @@ def single_process(args):
     res = {"metric": "MINCO traj-opts/sec (batch)", "value": B * N * args.steps / dt, "unit": "traj-opts/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "hill scene (synthetic hill cloud, map built on the devices by uph_map_build_multi), batch of %d random start/goal full ALM solves per GPU, run_hill.yaml params" % B,
-                      "batch_per_gpu": B, "grid": [nx, ny, int(m0.voxel_num[2])], "launcher": "single process, C-ABI multi-GPU entries (no torch.distributed)", "parallelism": "dp%d" % N},
+                      "batch_per_gpu": B, "grid": [nx, ny, int(m0.voxel_num[2])], "launcher": "single process, C-ABI multi-GPU entries (no torch.distributed)",
+                      "rccl_world": N if stages2.get("via_rccl") else 1, "parallelism": "dp%d" % N},
+           "per_rank_ms_per_step": [dt / args.steps * 1e3] * N,
            "per_gpu_kernel_ms": [float(v) for v in np.mean(np.array(kms), axis=0)], "converged_frac": float((rets == 0).mean()),
-           "map_build_multi": dict(first_call_s=map_build_s, warm_call_s=map_build_warm_s, first=stages, warm=stages2)}
+           "map_build_multi": dict(first_call_s=map_build_s, warm_call_s=map_build_warm_s, first=stages, warm=stages2,
+                                   per_device_slab_stages_ms=[mm.build_stats()["stages_ms"] for mm in maps],
+                                   note="first call includes the RCCL clique creation (~1 s) and the scratch allocations; the timed region never contains a map build")}
     print(json.dumps(res), flush=True)
 
 
@@ -451,6 +455,7 @@ def main():
             "lbfgs_iters_per_traj": iters / K / args.batch, "evals_per_traj": evals / K / args.batch,
             "scaling_kernel_ms": float(np.mean(prepare_ms)),
             "converged_frac": float((rets == 0).mean()), "map_build_s": map_build_s, "map_kernel_ms": map_stats["kernel_ms"],
+            "map_build_stages_ms": map_stats.get("stages_ms"),      # rank 0's uph_map_build (its x-slab when N > 1): upload, crop + voxel, bucketing, kernel, commit, call; map_build_s adds the all-gather and the download into numpy
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "uph_solver_kernel<%s,2> (ALM/L-BFGS solve)" % ("128,2" if args.batch >= 2304 else ("256,2" if args.batch >= 512 else "256,1")), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "frac_without_unwritten_residuals": moved_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

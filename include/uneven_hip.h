@@ -282,10 +282,14 @@ int64_t uph_map_built_cloud(uph_map* m, float* out_xyz, int64_t cap);
 /* ---- front end: KinoAstar::plan for a batch of queries, one wave64 per query (csrc/kino_search.hip).
  * uph_kino_create = KinoAstar::init + setEnvironment (kino_astar.cpp:5-43, kino_astar.h:170-178): parameters, the Dubins radius wheel_base / tan(max_steer),
  * a node pool of getXYNum() nodes per concurrent query.  slots = number of queries searched concurrently (each owns ~3.7 MB of HBM at 200 x 200 cells);
- * 0 = eight per compute unit.  The map must stay alive and must not be rebuilt while a search runs. */
+ * 0 = one per wave slot of the default kernel instantiation (16 per compute unit).  The map must stay alive and must not be rebuilt while a search runs. */
 int uph_kino_create(uph_map* m, const uph_kino_params* kp, int32_t slots, uph_kino** out);
 void uph_kino_destroy(uph_kino* k);
 int uph_kino_slots(const uph_kino* k);
+/* experiment knob: waves per SIMD the search kernel is compiled for -- 2, 4 (default), 6 or 8 (register caps 256 / 128 / 80 / 64) */
+int uph_kino_set_wps(uph_kino* k, int32_t wps);
+/* experiment knob: bit 0 = queries handed out dynamically, longest first (default on); bit 1 = sincosFast instead of the device library's sin / cos (default on) */
+int uph_kino_set_flags(uph_kino* k, int32_t flags);
 int uph_kino_primitives(const uph_kino* k);   /* motion primitives per expansion produced by the reference's loops (kino_astar.cpp:138-145): 15 */
 /* starts / goals [B][3] = (x, y, yaw): plan(start_state, end_state) per query.  paths [B][path_cap][3] receives front_end_path (the poses of the
  * node chain, then the Dubins shot samples, kino_astar.h:273-292), n_path[B] its length (may exceed path_cap: truncated), status[B] UPH_KINO_*;
@@ -306,6 +310,10 @@ void uph_ctx_destroy(uph_ctx* c);
  * 128 lanes with up to four workgroups per CU from 2304 problems (throughput), 256 lanes below, 512 lanes up to 256 problems (latency).  Takes effect at the next
  * upload.  Results do not depend on the choice beyond the summation order of the block reductions. */
 int uph_ctx_set_lanes(uph_ctx* c, int32_t lanes);
+/* experiment knob (takes effect at the next upload): group >= 16 permutes the launch order inside groups of `group` workgroups of similar predicted
+ * cost so that the workgroups dispatched to one XCD (workgroup index mod 8) work in one octant of the map (per-XCD L2 locality); 0 = off (default).
+ * Placement never changes results. */
+int uph_ctx_set_xcd_locality(uph_ctx* c, int32_t group);
 /* experiment knob: 2 = register-capped kernel build (two waves per SIMD), 1 = uncapped, 0 = choose from the batch size */
 int uph_ctx_set_wps(uph_ctx* c, int32_t wps);
 /* BASELINE.json configs[4] "fp32": bits = 32 makes the sample phase of the objective (polynomial evaluation, terrain lookup, penalties and

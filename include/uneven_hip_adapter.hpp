@@ -11,6 +11,8 @@
 //   getMaxVxAxAyCurAttSig         alm_traj_opt.h:170-229 (device report), init / setFrontend / visSE2Traj / visSE3Traj (no-ops here)
 //   Piece / PolyTrajectory / SE2Trajectory   back_end/include/utils/se2traj.hpp:30-150, 253-406, 408-562 (evaluation members, getNonHolError)
 //   mpc_controller/SE2Traj filler  plan_manager.cpp:150-182, mpc_controller/msg/SE2Traj.msg:1-9
+//   KinoAstar::plan / setEnvironment / init   front_end/include/front_end/kino_astar.h:147-154, front_end/src/kino_astar.cpp:5-43, 67-236
+//                                  (the batched device search, uph_kino_plan_batch; planBatch = many goals in one call)
 //
 // The matrix/vector types are template parameters: anything with data(), rows(), cols()/size() and column-major storage works
 // (Eigen::MatrixXd / Eigen::VectorXd in the ROS workspace; the tiny Mat/Vec below where Eigen is not installed, as in this
@@ -415,6 +417,65 @@ private:
     std::vector<double> cxy_, cyaw_, x_;
     std::vector<uph_ctx*> last_ctxs_;       // contexts holding the shares of the last optimizeSE2TrajBatch (this object's first)
     int last_B_ = 0;
+};
+
+
+// KinoAstar (front_end/include/front_end/kino_astar.h:99-168): the front-end PlanManager calls right before the back-end
+// (`kino_astar->plan(start_state, end_state)`, plan_manager.cpp:59-60).  Same public parameter members as the reference reads from rosparam
+// (kino_astar.cpp:7-20; defaults = run_hill.yaml:16-30), same plan() signature; the search runs on the device, one wave64 per query.
+class KinoAstar {
+public:
+    double yaw_resolution = 3.15, lambda_heu = 1.0, weight_r2 = 1.0, weight_so2 = 0.5, weight_v_change = 0.0, weight_delta_change = 0.0, weight_sigma = 10.0;
+    double time_interval = 0.3, collision_interval = 0.06, oneshot_range = 1.0, wheel_base = 0.26, max_steer = 0.5, max_vel = 0.5;
+
+    KinoAstar() = default;
+    ~KinoAstar() { if (k_) uph_kino_destroy(k_); }
+    KinoAstar(const KinoAstar&) = delete;
+    KinoAstar& operator=(const KinoAstar&) = delete;
+
+    template <class NodeHandle> void init(NodeHandle&) {}            // rosparam loading: set the public members instead (before setEnvironment)
+    void setEnvironment(UnevenMapHandle* env, int slots = 0) {        // kino_astar.h:170-178: binds the map, allocates the node pools
+        if (k_) { uph_kino_destroy(k_); k_ = nullptr; }
+        const uph_kino_params kp{yaw_resolution, lambda_heu, weight_r2, weight_so2, weight_v_change, weight_delta_change, weight_sigma,
+                                 time_interval, collision_interval, oneshot_range, wheel_base, max_steer, max_vel};
+        if (uph_kino_create(env->get(), &kp, slots, &k_) != UPH_OK) throw std::runtime_error(std::string("uph_kino_create: ") + uph_last_error());
+    }
+    // std::vector<Eigen::Vector3d> plan(const Eigen::Vector3d& start_state, const Eigen::Vector3d& end_state)   (kino_astar.cpp:67-236)
+    template <class V3>
+    std::vector<VecN<3>> plan(const V3& start_state, const V3& end_state) {
+        std::vector<std::vector<VecN<3>>> r = planBatch(std::vector<V3>(1, start_state), std::vector<V3>(1, end_state));
+        front_end_path = r[0];
+        return front_end_path;
+    }
+    // many goals at once: paths[b] is empty where the reference would return an empty vector (start / goal occupied, no path, pool exhausted);
+    // status[b] says which (UPH_KINO_*)
+    template <class V3>
+    std::vector<std::vector<VecN<3>>> planBatch(const std::vector<V3>& starts, const std::vector<V3>& goals, int path_cap = 2048) {
+        if (!k_) throw std::runtime_error("KinoAstar: setEnvironment has not been called");
+        const int32_t B = (int32_t)starts.size();
+        std::vector<std::vector<VecN<3>>> out((size_t)B);
+        status.assign((size_t)B, 0); iter_num.assign((size_t)B, 0);
+        if (B == 0 || goals.size() != starts.size()) return out;
+        std::vector<double> s((size_t)3 * B), g((size_t)3 * B), paths((size_t)3 * B * path_cap);
+        std::vector<int32_t> np(B), use(B);
+        for (int32_t b = 0; b < B; b++) for (int k = 0; k < 3; k++) { s[(size_t)3 * b + k] = starts[b][k]; g[(size_t)3 * b + k] = goals[b][k]; }
+        if (uph_kino_plan_batch(k_, B, s.data(), g.data(), path_cap, paths.data(), np.data(), status.data(), iter_num.data(), use.data(), 0, 0, nullptr) != UPH_OK)
+            throw std::runtime_error(std::string("uph_kino_plan_batch: ") + uph_last_error());
+        for (int32_t b = 0; b < B; b++) {
+            if (status[b] != UPH_KINO_OK) continue;
+            const int n = np[b] < path_cap ? np[b] : path_cap;
+            out[b].resize((size_t)n);
+            for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) out[b][i][k] = paths[((size_t)b * path_cap + i) * 3 + k];
+        }
+        return out;
+    }
+    std::vector<VecN<3>> front_end_path;
+    std::vector<int32_t> status, iter_num;      // of the last plan / planBatch
+    void visFrontEnd() {}                        // RViz output stays with the host (no device side)
+    void visExpanded() {}
+
+private:
+    uph_kino* k_ = nullptr;
 };
 
 }  // namespace uneven_hip

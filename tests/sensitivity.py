@@ -89,9 +89,10 @@ def _binom_two_sided(k, n):
     """exact two-sided binomial p-value for k successes of n at p = 1/2 (McNemar's exact test / the sign test)"""
     if n == 0:
         return 1.0
-    from math import comb
+    from math import exp, lgamma, log
     k = min(k, n - k)
-    return float(min(1.0, 2.0 * sum(comb(n, i) for i in range(k + 1)) / 2.0 ** n))
+    tail = sum(exp(lgamma(n + 1) - lgamma(i + 1) - lgamma(n - i + 1) - n * log(2.0)) for i in range(k + 1))      # (log domain: n reaches the thousands)
+    return float(min(1.0, 2.0 * tail))
 
 
 def paired_counts(ref, other):

@@ -110,6 +110,18 @@ int plan_once(UnevenMapHandle& map, const Mat& init_xy, const Mat& end_xy, const
     return rc + (traj_opt.getTrajJerkCost() > 0 ? 0 : 10);
 }
 
+// the front end in front of it (plan_manager.cpp:56-60): kino_astar->plan(start_state, end_state) for one goal and for many
+std::vector<std::vector<VecN<3>>> search_many(UnevenMapHandle& map, const std::vector<VecN<3>>& starts, const std::vector<VecN<3>>& goals) {
+    KinoAstar kino_astar;
+    FakeNodeHandle nh;
+    kino_astar.init(nh);
+    kino_astar.weight_sigma = 10.0;
+    kino_astar.setEnvironment(&map);
+    std::vector<VecN<3>> init_path = kino_astar.plan(starts[0], goals[0]);
+    if (init_path.empty()) std::printf("front end failed: status %d\n", kino_astar.status[0]);
+    return kino_astar.planBatch(starts, goals);
+}
+
 // many candidate goals at once: the front-end's pose lists go in, one trajectory and return code per goal comes out
 ALMTrajOpt::BatchPlan plan_many(UnevenMapHandle& map, const std::vector<std::vector<VecN<3>>>& paths) {
     ALMTrajOpt traj_opt;

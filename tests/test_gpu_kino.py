@@ -82,7 +82,9 @@ def test_refusals_dead_ends_and_slot_reuse(oracle, analytic_cells):
     m = U.UnevenMap(device=0)
     cells = analytic_cells.reshape(200, 200, 64, 4).copy()
     cells[118:123, 118:123, :, 1] = 1.0                # sigma = 1 > max_rho: a 5 x 5 block of occupied columns around (1.0, 1.0) ...
-    cells[60:81, 60, :, 1] = 1.0; cells[60:81, 80, :, 1] = 1.0; cells[60, 60:81, :, 1] = 1.0; cells[80, 60:81, :, 1] = 1.0      # ... and a closed wall around (-1.5, -1.5)
+    # ... and a closed wall around (-1.5, -1.5), FOUR cells = 0.2 m thick: the reference samples a primitive for collisions every 0.06 m of arc only
+    # (kino_astar.cpp:173-183) and never its end state, so it tunnels through a one-cell wall
+    cells[58:83, 58:62, :, 1] = 1.0; cells[58:83, 79:83, :, 1] = 1.0; cells[58:62, 58:83, :, 1] = 1.0; cells[79:83, 58:83, :, 1] = 1.0
     m.set_cells(cells.reshape(-1, 4))
     g = oracle.OracleGrid()
     g.set_cells(m.map_buffer)
@@ -97,7 +99,7 @@ def test_refusals_dead_ends_and_slot_reuse(oracle, analytic_cells):
     want = [ok.plan(s, gl) for s, gl in zip(S, G)]
     assert [w["status"] for w in want][:2] == [1, 2]
     assert want[2]["status"] in (3, 4)                 # the walled-in goal is never reached
-    assert want[4]["status"] == 0                      # inside the wall, start and goal together: fine
+    assert want[4]["status"] in (0, 3)                 # inside the wall, start and goal together: a 0.85 m yard -- the open set soon runs empty
     for b, (d, w) in enumerate(zip(dev, want)):
         _same(d, w, "query %d" % b)
     # the same batch with one query per wave: identical results (workspaces are fully re-initialised between queries)

@@ -27,6 +27,8 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     scene = sys.argv[3] if len(sys.argv) > 3 else "hill"
     global PARAM_SETS
+    if os.environ.get("UPH_PB_ONLY_YAML"):           # the shipped parameter set only (large-N drift statistics)
+        PARAM_SETS = PARAM_SETS[:1]
     if scene == "hill":
         m = U.UnevenMap()
         m.build(scenes.make_hill_cloud())

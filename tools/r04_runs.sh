@@ -43,5 +43,94 @@ print("drift", json.dumps(r.get("parity_floor", {}).get("drift")))
 PY
 tail -3 $OUT/bench.err
 ;;
+3)
+# kino tests again, the whole GPU tier (device-side cloud filter, empty-share fix), the stage breakdown of the map build, and the drift statistics at N = 1024
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r04c; mkdir -p $OUT
+make -C oracle -s 2>&1 | tail -2
+timeout 1200 python -m pytest tests -m gpu -q -x > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -25 $OUT/gpu_tests.txt | cut -c1-300
+python - <<'PY' | tee $OUT/map_stages.txt
+import time, numpy as np
+import uneven_planner_amd as U
+from uneven_planner_amd import scenes
+xyz = scenes.make_hill_cloud()
+m = U.UnevenMap()
+for k in range(3):
+    t0 = time.perf_counter(); m.build(xyz, download=False); t1 = time.perf_counter(); m.download(); t2 = time.perf_counter()
+    print("build %d: uph_map_build %.2f ms (stages %s)  + download of cells / c / occupancy into numpy %.2f ms" % (k, (t1 - t0) * 1e3, {a: round(b, 3) for a, b in m.build_stats()["stages_ms"].items()}, (t2 - t1) * 1e3))
+PY
+UPH_PB_ONLY_YAML=1 timeout 900 python tools/parity_buckets.py 1024 $OUT/parity_buckets_hill_1024.json hill > $OUT/parity_buckets_hill_1024.txt 2>&1
+tail -12 $OUT/parity_buckets_hill_1024.txt | cut -c1-500
+;;
+4)
+# whole GPU tier (no -x), drift statistics at N = 1024, front-end throughput over the kernel's register budgets
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r04d; mkdir -p $OUT
+make -C oracle -s 2>&1 | tail -2
+timeout 1500 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -12 $OUT/gpu_tests.txt | cut -c1-300
+python - <<'PY' | tee $OUT/kino_wps.txt
+import time, numpy as np
+import uneven_planner_amd as U
+from uneven_planner_amd import scenes
+m = U.UnevenMap(); m.build(scenes.make_hill_cloud())
+nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
+S, G = scenes.random_queries(8192, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
+ka = U.KinoAstar(m, slots=8192)
+base = None
+for wps in (2, 4, 6, 8):
+    ka.set_wps(wps)
+    ka.plan_batch(S[:256], G[:256], path_cap=1)
+    for B in (1, 2048, 8192):
+        t0 = time.perf_counter(); r = ka.plan_batch(S[:B], G[:B], path_cap=256); dt = time.perf_counter() - t0
+        it = np.array([q["iter_num"] for q in r]); st = np.array([q["status"] for q in r])
+        if wps == 2 and B == 8192: base = (it.copy(), st.copy())
+        same = "" if base is None or B != 8192 else (" identical to wps 2: %s" % (np.array_equal(it, base[0]) and np.array_equal(st, base[1])))
+        print("wps %d B %5d: %8.0f queries/s  kernel %.1f ms  %.2f M expansions/s  max expansions %d%s" % (wps, B, B / dt, ka.stats()["kernel_ms"], it.sum() / dt / 1e6, it.max(), same))
+PY
+UPH_PB_ONLY_YAML=1 timeout 900 python tools/parity_buckets.py 1024 $OUT/parity_buckets_hill_1024.json hill > $OUT/parity_buckets_hill_1024.txt 2>&1
+tail -12 $OUT/parity_buckets_hill_1024.txt | cut -c1-600
+;;
+5)
+# the search kernel's configurations one process each, every one under its own short timeout (call 4 ran into a kernel that never ended)
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r04e; mkdir -p $OUT
+make -C oracle -s 2>&1 | tail -2
+for cfg in "2 0" "2 2" "2 1" "2 3" "4 3" "6 3" "8 3"; do
+  timeout 100 python tools/kino_probe.py $cfg 8192 2>&1 | tail -1 | cut -c1-400; echo "  (cfg $cfg rc $?)"
+done | tee $OUT/kino_probe.txt
+timeout 300 python -m pytest tests/test_gpu_kino.py -q 2>&1 | tail -5 | cut -c1-300 | tee $OUT/kino_tests.txt
+;;
+6)
+# whole GPU tier, front-end throughput at batch sizes beyond the slot count (load balance), XCD-local launch order A/B, single-trajectory phases,
+# drift statistics at N = 1024
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r04f; mkdir -p $OUT
+make -C oracle -s 2>&1 | tail -2
+timeout 900 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -8 $OUT/gpu_tests.txt | cut -c1-300
+for cfg in "2 3" "4 3"; do timeout 200 python tools/kino_probe.py $cfg 65536 2>&1 | tail -1 | cut -c1-600; done | tee $OUT/kino_big.txt
+UPH_KINO_SLOTS=2048 timeout 200 python tools/kino_probe.py 4 3 65536 2>&1 | tail -1 | cut -c1-600 | tee -a $OUT/kino_big.txt
+python - <<'PY' | tee $OUT/xcd_ab.txt
+import time, numpy as np
+import uneven_planner_amd as U
+from uneven_planner_amd import scenes
+m = U.UnevenMap(); m.build(scenes.make_hill_cloud())
+nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
+probs = scenes.random_problems(16384, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
+for grp in (0, 64, 256, 0, 64, 256):
+    o = U.ALMTrajOpt(m); o.set_xcd_locality(grp); o.upload(probs)
+    o.set_rho(1.0); o.solve()
+    ms = []
+    for _ in range(3):
+        o.set_rho(1.0); o.solve(); ms.append(o.stats()["kernel_ms"])
+    print("xcd_group %3d: solve kernel %.1f ms (B = 16384, %s)" % (grp, np.mean(ms), ["%.1f" % v for v in ms]))
+    del o
+PY
+UPH_LANES=512 timeout 100 python tools/phase_breakdown.py 1 2>&1 | grep -E "cycles/eval|kernel_ms" | tee $OUT/single_phases.txt
+UPH_PB_ONLY_YAML=1 timeout 600 python tools/parity_buckets.py 1024 $OUT/parity_buckets_hill_1024.json hill > $OUT/parity_buckets_hill_1024.txt 2>&1
+tail -12 $OUT/parity_buckets_hill_1024.txt | cut -c1-700
+;;
 *) echo "usage: tools/r04_runs.sh <n>";;
 esac

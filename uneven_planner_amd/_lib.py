@@ -106,6 +106,7 @@ SYMBOLS = {
     "uph_ctx_destroy": (None, [_VP]),
     "uph_ctx_set_lanes": (C.c_int, [_VP, _I32]),
     "uph_ctx_set_wps": (C.c_int, [_VP, _I32]),
+    "uph_ctx_set_xcd_locality": (C.c_int, [_VP, _I32]),
     "uph_ctx_set_sample_precision": (C.c_int, [_VP, _I32]),
     "uph_ctx_set_rho": (C.c_int, [_VP, C.c_double]),
     "uph_ctx_get_rho": (C.c_int, [_VP, DP]),
@@ -133,6 +134,8 @@ SYMBOLS = {
     "uph_kino_create": (C.c_int, [_VP, C.POINTER(KinoParams), _I32, C.POINTER(_VP)]),
     "uph_kino_destroy": (None, [_VP]),
     "uph_kino_slots": (C.c_int, [_VP]),
+    "uph_kino_set_wps": (C.c_int, [_VP, _I32]),
+    "uph_kino_set_flags": (C.c_int, [_VP, _I32]),
     "uph_kino_primitives": (C.c_int, [_VP]),
     "uph_kino_plan_batch": (C.c_int, [_VP, _I32, DP, DP, _I32, DP, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), _I32, _I32, C.POINTER(_I32)]),
     "uph_kino_stats": (C.c_int, [_VP, DP]),

@@ -128,6 +128,10 @@ class ALMTrajOpt:
         """64 / 128 / 256 lanes (one / two / four waves) per trajectory, 0 = automatic"""
         _lib.check(self.L.uph_ctx_set_lanes(self.h, int(lanes)), "uph_ctx_set_lanes")
 
+    def set_xcd_locality(self, group):
+        """experiment knob: per-XCD L2 locality of the launch order (uph_ctx_set_xcd_locality); takes effect at the next upload"""
+        _lib.check(self.L.uph_ctx_set_xcd_locality(self.h, int(group)), "uph_ctx_set_xcd_locality")
+
     def set_wps(self, wps):
         _lib.check(self.L.uph_ctx_set_wps(self.h, int(wps)), "uph_ctx_set_wps")
 

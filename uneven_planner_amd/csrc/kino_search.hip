@@ -30,6 +30,7 @@
 // cited lines.  tan(steer) of the primitives and their collision sample times are formed on the host by the reference's own loops.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -91,6 +92,7 @@ struct KinoIO {
     int* n_path; int* status; int* iter_num; int* use_node_num;      // [B]
     int* expanded; int exp_cap;                    // [B][exp_cap][3] or null
     int max_expand;
+    const int* order; int* next;                   // launch order of the queries [B], shared cursor
 };
 
 __device__ __forceinline__ int kuni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -108,23 +110,33 @@ __device__ __forceinline__ int kFloorToInt(double v) {          // (int)floor(v)
     return (int)f;
 }
 __device__ __forceinline__ double kNormalizeAngle(double angle) {      // kino_astar.h:193-204
-    double a = angle;
-    while (a > 3.14159265358979323846) a -= 6.283185307179586;
-    while (a < -3.14159265358979323846) a += 6.283185307179586;
+    double a = angle;                          // (bounded like normSO2 in uph_common.hpp: an absurd angle cannot hang a wave; the search's angles stay within a few turns)
+    for (int it = 0; it < 4096 && a > 3.14159265358979323846; it++) a -= 6.283185307179586;
+    for (int it = 0; it < 4096 && a < -3.14159265358979323846; it++) a += 6.283185307179586;
     return a;
 }
-// kino_astar.h:218-240 with tan(delta) handed in (formed on the host)
-__device__ __forceinline__ void kStateTransit(const KinoDev& P, double x0, double y0, double w0, double v, double delta, double tand, double T, double& x1, double& y1, double& w1) {
+// kino_astar.h:218-240 with tan(delta) handed in (formed on the host) and sin / cos of the node's own heading (sw0, cw0: the same for every
+// primitive and collision sample of an expansion) computed once; sincosFast: fdlibm kernels, < 0.8 ulp (uph_common.hpp)
+template <bool FAST>
+__device__ __forceinline__ void kSinCos(double x, double& sn, double& cs) {
+    if (FAST) sincosFast(x, sn, cs);
+    else { sn = sin(x); cs = cos(x); }
+}
+template <bool FAST>
+__device__ __forceinline__ void kStateTransit(const KinoDev& P, double x0, double y0, double w0, double sw0, double cw0, double v, double delta, double tand, double T, double& x1, double& y1,
+                                              double& w1) {
     const double s = v * T;
     const double y = s * tand / P.wheel_base;
     if (fabs(delta) > 1e-4) {
         const double r = s / y;
-        x1 = x0 + r * (sin(w0 + y) - sin(w0));
-        y1 = y0 - r * (cos(w0 + y) - cos(w0));
+        double sw1, cw1;
+        kSinCos<FAST>(w0 + y, sw1, cw1);
+        x1 = x0 + r * (sw1 - sw0);
+        y1 = y0 - r * (cw1 - cw0);
         w1 = kNormalizeAngle(w0 + y);
     } else {
-        x1 = x0 + s * cos(w0);
-        y1 = y0 + s * sin(w0);
+        x1 = x0 + s * cw0;
+        y1 = y0 + s * sw0;
         w1 = w0;
     }
 }
@@ -278,7 +290,7 @@ __device__ __forceinline__ void kHeapPop(KHeap* heap, int* pos, int n, int lane)
     KHeap mine; mine.f = 0.0; mine.id = -1; mine.pad = 0;      // lane k: E_k
     int my_p = -1, my_pp = -1;                                   // p_k, p_{k-1}
     int hole = 0, second = 0, L = 0;
-    while (second < (len - 1) / 2) {
+    while (second < (len - 1) / 2 && L < 60) {
         second = 2 * (second + 1);
         const KHeap r = heap[second], l = heap[second - 1];      // (uniform addresses: one transaction each)
         const double rf = kuni(r.f), lf = kuni(l.f);
@@ -306,7 +318,13 @@ __device__ __forceinline__ void kHeapPop(KHeap* heap, int* pos, int n, int lane)
 }
 
 // ------------------------------------------------------------------------------------------------ the search kernel: one wave64 per query
-__global__ __launch_bounds__(64) void uph_kino_kernel(GridDev g, const char* __restrict__ occ, const char* __restrict__ occ2, const KinoDev* __restrict__ Pp, KinoWork W, size_t node_stride,
+#ifndef UPH_KINO_WPS
+#define UPH_KINO_WPS 4            // default waves per SIMD of the search kernel (register cap 512 / WPS): the search is latency-bound, residency is what scales it
+#endif
+// WPS = waves per SIMD the instantiation is compiled for (uph_kino_set_wps picks one: 2 = 256 registers, 4 = 128, 6 = 80, 8 = 64);
+// FAST = sincosFast (fdlibm kernels, uph_common.hpp) instead of the device library's sin / cos
+template <int WPS, bool FAST>
+__global__ __launch_bounds__(64, WPS) void uph_kino_kernel(GridDev g, const char* __restrict__ occ, const char* __restrict__ occ2, const KinoDev* __restrict__ Pp, KinoWork W, size_t node_stride,
                                                       size_t heap_stride, size_t table_stride, KinoIO io, int B) {
     const int lane = threadIdx.x;
     const KinoDev& P = *Pp;
@@ -315,7 +333,17 @@ __global__ __launch_bounds__(64) void uph_kino_kernel(GridDev g, const char* __r
     int* pos = W.pos + (size_t)blockIdx.x * node_stride;
     int* nkey = W.key + (size_t)blockIdx.x * node_stride;
     int* table = W.table + (size_t)blockIdx.x * table_stride;
-    for (int q = blockIdx.x; q < B; q += gridDim.x) {
+    // queries are handed out dynamically, longest (by straight-line distance) first: io.order is that order, io.next the shared cursor
+    // (io.next == nullptr: static assignment, query blockIdx.x + k gridDim.x of the order)
+    for (int turn = 0; turn <= B; turn++) {                       // (a wave can take at most B queries: the bound is a guard)
+        int qi = blockIdx.x + turn * (int)gridDim.x;
+        if (io.next != nullptr) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(io.next, 1);
+            qi = kuni(t);
+        }
+        if (qi >= B) break;
+        const int q = io.order[qi];
         const double sx0 = io.starts[3 * q], sy0 = io.starts[3 * q + 1], sw0 = io.starts[3 * q + 2];
         const double gx = io.goals[3 * q], gy = io.goals[3 * q + 1], gw = io.goals[3 * q + 2];
         int status = -1, iter_num = 0, use_node_num = 0, n = 0, n_path = 0;
@@ -344,6 +372,7 @@ __global__ __launch_bounds__(64) void uph_kino_kernel(GridDev g, const char* __r
         }
         while (status < 0) {
             if (n == 0) { status = 3; break; }                                             // :111, :233
+            if (iter_num > 2 * P.allocate_num) { status = 6; break; }                      // (cannot happen: every pop consumes a push and pushes stop at allocate_num -- a guard, not a rule)
             const int cur = kuni(heap[0].id);
             const KNode cn = nodes[cur];
             const double cx = kuni(cn.sx), cy = kuni(cn.sy), cw = kuni(cn.syaw), cg = kuni(cn.g), civ = kuni(cn.in_v), cis = kuni(cn.in_steer);
@@ -369,13 +398,13 @@ __global__ __launch_bounds__(64) void uph_kino_kernel(GridDev g, const char* __r
                     if (!__ballot(blocked) && M > 0) {
                         // retrievePath (kino_astar.h:273-292): root .. cur, then the shot samples
                         int depth = 0;
-                        if (lane == 0) { for (int v = cur; v >= 0; v = nodes[v].parent) depth++; }
+                        if (lane == 0) { for (int v = cur; v >= 0 && depth < P.allocate_num; v = nodes[v].parent) depth++; }
                         depth = kuni(depth);
                         n_path = depth + M;
                         double* out = io.paths + (size_t)q * io.path_cap * 3;
                         if (lane == 0) {
                             int at = depth - 1;
-                            for (int v = cur; v >= 0; v = nodes[v].parent, at--) {
+                            for (int v = cur; v >= 0 && at >= 0; v = nodes[v].parent, at--) {
                                 if (at < io.path_cap) { out[3 * at] = nodes[v].sx; out[3 * at + 1] = nodes[v].sy; out[3 * at + 2] = nodes[v].syaw; }
                             }
                         }
@@ -404,6 +433,8 @@ __global__ __launch_bounds__(64) void uph_kino_kernel(GridDev g, const char* __r
             iter_num++;
             if (io.max_expand > 0 && iter_num >= io.max_expand) { status = 5; break; }
             // ---- the primitives of this node, one per lane (:147-195)
+            double csw, ccw;
+            kSinCos<FAST>(cw, csw, ccw);
             bool act = false;
             double px = 0.0, py = 0.0, pw = 0.0, tg = 0.0, tf = 0.0, iv = 0.0, is = 0.0;
             int key = -1, pre = -1, pre_flag = 0;
@@ -411,7 +442,7 @@ __global__ __launch_bounds__(64) void uph_kino_kernel(GridDev g, const char* __r
             if (lane < P.n_inputs) {
                 iv = P.in_v[lane]; is = P.in_steer[lane];
                 const double tand = P.in_tan[lane];
-                kStateTransit(P, cx, cy, cw, iv, is, tand, P.time_interval, px, py, pw);
+                kStateTransit<FAST>(P, cx, cy, cw, csw, ccw, iv, is, tand, P.time_interval, px, py, pw);
                 if (isInMap<double>(g, px, py, pw)) {                                      // :154-158
                     int id3[3];
                     key = kKey(g, P, px, py, pw, id3);
@@ -422,7 +453,7 @@ __global__ __launch_bounds__(64) void uph_kino_kernel(GridDev g, const char* __r
                     const int nt = P.in_nt[lane];
                     for (int s = 0; s < nt && !closed; s++) {                              // :171-185
                         double xt, yt, wt;
-                        kStateTransit(P, cx, cy, cw, iv, is, tand, P.in_t[lane][s], xt, yt, wt);
+                        kStateTransit<FAST>(P, cx, cy, cw, csw, ccw, iv, is, tand, P.in_t[lane][s], xt, yt, wt);
                         occv = kOccXY(g, occ2, xt, yt, wt);
                         if (occv == 1) break;
                     }
@@ -491,11 +522,11 @@ struct uph_kino {
     uph_map* map = nullptr;
     int device = 0;
     KinoDev P;
-    int slots = 0;
+    int slots = 0, wps = UPH_KINO_WPS, flags = 3;      // flags: bit 0 = dynamic query hand-out, bit 1 = sincosFast
     size_t node_stride = 0, heap_stride = 0, table_stride = 0;
     void *d_P = nullptr, *d_nodes = nullptr, *d_heap = nullptr, *d_pos = nullptr, *d_key = nullptr, *d_table = nullptr;
-    void *d_io[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t io_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void *d_io[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t io_cap[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     double last_ms = 0.0;
 };
@@ -546,7 +577,7 @@ int uph_kino_create(uph_map* m, const uph_kino_params* kp, int32_t slots, uph_ki
     if (slots == 0) {
         hipDeviceProp_t prop;
         KHIPCHK(hipGetDeviceProperties(&prop, k->device));
-        slots = prop.multiProcessorCount * 8;                               // eight waves per CU: the search is latency-bound, the CU has slots to spare
+        slots = prop.multiProcessorCount * 4 * UPH_KINO_WPS;                // one workspace per wave slot of the default instantiation
     }
     k->slots = slots;
     k->node_stride = (size_t)P.allocate_num;
@@ -569,13 +600,21 @@ void uph_kino_destroy(uph_kino* k) {
     if (!k) return;
     hipSetDevice(k->device);
     hipFree(k->d_P); hipFree(k->d_nodes); hipFree(k->d_heap); hipFree(k->d_pos); hipFree(k->d_key); hipFree(k->d_table);
-    for (int i = 0; i < 8; i++) hipFree(k->d_io[i]);
+    for (int i = 0; i < 10; i++) hipFree(k->d_io[i]);
     if (k->e0) hipEventDestroy(k->e0);
     if (k->e1) hipEventDestroy(k->e1);
     delete k;
 }
 
 int uph_kino_slots(const uph_kino* k) { return k ? k->slots : UPH_ERR_INVALID; }
+// experiment knob: which instantiation of the search kernel runs -- 2, 4, 6 or 8 waves per SIMD (register caps 256 / 128 / 80 / 64)
+// experiment knob: bit 0 = queries handed out dynamically (longest first) instead of statically, bit 1 = sincosFast instead of the device library's sin / cos
+int uph_kino_set_flags(uph_kino* k, int32_t flags) { if (!k || flags < 0 || flags > 3) return UPH_ERR_INVALID; k->flags = flags; return UPH_OK; }
+int uph_kino_set_wps(uph_kino* k, int32_t wps) {
+    if (!k || (wps != 2 && wps != 4 && wps != 6 && wps != 8)) { setError("uph_kino_set_wps: 2, 4, 6 or 8"); return UPH_ERR_INVALID; }
+    k->wps = wps;
+    return UPH_OK;
+}
 int uph_kino_primitives(const uph_kino* k) { return k ? k->P.n_inputs : UPH_ERR_INVALID; }
 
 int uph_kino_plan_batch(uph_kino* k, int32_t B, const double* starts, const double* goals, int32_t path_cap, double* paths, int32_t* n_path, int32_t* status,
@@ -584,9 +623,9 @@ int uph_kino_plan_batch(uph_kino* k, int32_t B, const double* starts, const doub
         setError("uph_kino_plan_batch: bad arguments"); return UPH_ERR_INVALID;
     }
     KHIPCHK(hipSetDevice(k->device));
-    const size_t need[8] = {sizeof(double) * 3 * (size_t)B, sizeof(double) * 3 * (size_t)B, sizeof(double) * 3 * (size_t)B * (size_t)std::max(1, path_cap), sizeof(int) * (size_t)B,
-                            sizeof(int) * (size_t)B, sizeof(int) * (size_t)B, sizeof(int) * (size_t)B, sizeof(int) * 3 * (size_t)B * (size_t)std::max(1, exp_cap)};
-    for (int i = 0; i < 8; i++) {
+    const size_t need[10] = {sizeof(double) * 3 * (size_t)B, sizeof(double) * 3 * (size_t)B, sizeof(double) * 3 * (size_t)B * (size_t)std::max(1, path_cap), sizeof(int) * (size_t)B,
+                             sizeof(int) * (size_t)B, sizeof(int) * (size_t)B, sizeof(int) * (size_t)B, sizeof(int) * 3 * (size_t)B * (size_t)std::max(1, exp_cap), sizeof(int) * (size_t)B, sizeof(int)};
+    for (int i = 0; i < 10; i++) {
         if (need[i] <= k->io_cap[i]) continue;
         if (k->d_io[i]) hipFree(k->d_io[i]);
         k->d_io[i] = nullptr; k->io_cap[i] = 0;
@@ -596,12 +635,22 @@ int uph_kino_plan_batch(uph_kino* k, int32_t B, const double* starts, const doub
     }
     KHIPCHK(hipMemcpy(k->d_io[0], starts, need[0], hipMemcpyHostToDevice));
     KHIPCHK(hipMemcpy(k->d_io[1], goals, need[1], hipMemcpyHostToDevice));
+    {   // longest searches first (the expansion count grows with the start-goal distance), handed out from a shared cursor: the launch ends with short ones
+        std::vector<int> order((size_t)B);
+        std::vector<double> dist((size_t)B);
+        for (int b = 0; b < B; b++) { order[b] = b; const double dx = goals[3 * b] - starts[3 * b], dy = goals[3 * b + 1] - starts[3 * b + 1]; dist[b] = dx * dx + dy * dy; }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return dist[a] > dist[b2]; });
+        const int zero = 0;
+        KHIPCHK(hipMemcpy(k->d_io[8], order.data(), need[8], hipMemcpyHostToDevice));
+        KHIPCHK(hipMemcpy(k->d_io[9], &zero, sizeof(int), hipMemcpyHostToDevice));
+    }
     KinoIO io;
     io.starts = (const double*)k->d_io[0]; io.goals = (const double*)k->d_io[1];
     io.paths = (double*)k->d_io[2]; io.path_cap = path_cap;
     io.n_path = (int*)k->d_io[3]; io.status = (int*)k->d_io[4]; io.iter_num = (int*)k->d_io[5]; io.use_node_num = (int*)k->d_io[6];
     io.expanded = exp_cap > 0 ? (int*)k->d_io[7] : nullptr; io.exp_cap = exp_cap;
     io.max_expand = max_expand;
+    io.order = (const int*)k->d_io[8]; io.next = (k->flags & 1) ? (int*)k->d_io[9] : nullptr;
     KinoWork W;
     W.nodes = (KNode*)k->d_nodes; W.heap = (KHeap*)k->d_heap; W.pos = (int*)k->d_pos; W.key = (int*)k->d_key; W.table = (int*)k->d_table;
     W.table_len = ((size_t)k->P.nxy + 1) * k->P.nyawk;
@@ -609,7 +658,14 @@ int uph_kino_plan_batch(uph_kino* k, int32_t B, const double* starts, const doub
     uphMapOcc(k->map, &occ, &occ2);
     const int grid = std::min((int)B, k->slots);
     KHIPCHK(hipEventRecord(k->e0, 0));
-    hipLaunchKernelGGL(uph_kino_kernel, dim3(grid), dim3(64), 0, 0, uphMapGrid(k->map), occ, occ2, (const KinoDev*)k->d_P, W, k->node_stride, k->heap_stride, k->table_stride, io, (int)B);
+#define UPH_KINO_LAUNCH2(WPS_, F_) hipLaunchKernelGGL((uph_kino_kernel<WPS_, F_>), dim3(grid), dim3(64), 0, 0, uphMapGrid(k->map), occ, occ2, (const KinoDev*)k->d_P, W, k->node_stride, k->heap_stride, k->table_stride, io, (int)B)
+#define UPH_KINO_LAUNCH(WPS_) do { if (k->flags & 2) UPH_KINO_LAUNCH2(WPS_, true); else UPH_KINO_LAUNCH2(WPS_, false); } while (0)
+    if (k->wps == 2) UPH_KINO_LAUNCH(2);
+    else if (k->wps == 6) UPH_KINO_LAUNCH(6);
+    else if (k->wps == 8) UPH_KINO_LAUNCH(8);
+    else UPH_KINO_LAUNCH(4);
+#undef UPH_KINO_LAUNCH2
+#undef UPH_KINO_LAUNCH
     KHIPCHK(hipGetLastError());
     KHIPCHK(hipEventRecord(k->e1, 0));
     KHIPCHK(hipDeviceSynchronize());

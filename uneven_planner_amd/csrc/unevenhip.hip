@@ -677,6 +677,7 @@ struct uph_ctx {
     bool all_rejected = false;              // the last upload failed because EVERY problem was unsupported (not because of a misuse or a resource limit)
     std::vector<int> origin;                // batch loaded by uph_optimize_batch_multi: the caller's index of each problem of this context's share (empty: identity)
     bool sample_f32 = false;                // fp32 sample arithmetic (uph_ctx_set_sample_precision)
+    int xcd_group = 0;                      // experiment knob (uph_ctx_set_xcd_locality): > 0 = permute the launch order inside groups of that many workgroups for per-XCD L2 locality
     hipStream_t stream2 = nullptr;
     hipEvent_t evp0 = nullptr, evp1 = nullptr;      // prepare launch of an asynchronous solve
     bool pending = false;                   // uph_batch_solve_async issued, uph_batch_wait not yet called
@@ -918,6 +919,7 @@ int uph_ctx_set_lanes(uph_ctx* c, int32_t lanes) {
     c->lanes_forced = lanes;
     return UPH_OK;
 }
+int uph_ctx_set_xcd_locality(uph_ctx* c, int32_t group) { if (!c || group < 0) return UPH_ERR_INVALID; c->xcd_group = group; return UPH_OK; }
 int uph_ctx_set_wps(uph_ctx* c, int32_t wps) { if (!c || wps < 0 || wps > 2) return UPH_ERR_INVALID; c->wps_forced = wps; return UPH_OK; }
 int uph_ctx_set_sample_precision(uph_ctx* c, int32_t bits) {
     if (!c || (bits != 32 && bits != 64)) { setError("uph_ctx_set_sample_precision: 32 or 64"); return UPH_ERR_INVALID; }
@@ -1051,6 +1053,32 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         c->order.resize(B);
         std::iota(c->order.begin(), c->order.end(), 0);
         std::stable_sort(c->order.begin(), c->order.end(), [&](int a, int b2) { return cost[a] > cost[b2]; });
+        // Experiment: workgroup w is dispatched to XCD w % 8, each XCD has its own 4 MB L2, and the grid (82 MB) is shared.
+        // Inside groups of xcd_group consecutive entries of the cost order (similar predicted cost: the LPT property survives), entries are dealt
+        // to the residues w % 8 by the map octant (x half, y quarter) of their path's midpoint, so that the workgroups of one XCD read one region.
+        if (c->xcd_group >= 16) {
+            const GridDev gg = uphMapGrid(c->map);
+            auto octant = [&](int b) {
+                const uph_problem& q = *pp[b];
+                const double mx = 0.5 * (q.init_xy[0] + q.end_xy[0]), my = 0.5 * (q.init_xy[1] + q.end_xy[1]);
+                const int ix = mx < 0.5 * (gg.minb[0] + gg.maxb[0]) ? 0 : 1;
+                int iy = (int)((my - gg.minb[1]) / (gg.maxb[1] - gg.minb[1]) * 4.0);
+                iy = iy < 0 ? 0 : (iy > 3 ? 3 : iy);
+                return ix * 4 + iy;
+            };
+            const int G = c->xcd_group & ~7;
+            for (int g0 = 0; g0 + G <= B; g0 += G) {
+                std::vector<int> bins[8], spill, placed((size_t)G, -1);
+                for (int k = 0; k < G; k++) bins[octant(c->order[g0 + k])].push_back(c->order[g0 + k]);
+                for (int r = 0; r < 8; r++) {                                      // residue r takes its octant's entries first (cost order kept inside a bin)
+                    int at = r;
+                    for (int b : bins[r]) { if (at < G) { placed[at] = b; at += 8; } else spill.push_back(b); }
+                }
+                size_t sp = 0;
+                for (int k = 0; k < G; k++) if (placed[k] < 0) placed[k] = spill[sp++];
+                for (int k = 0; k < G; k++) c->order[g0 + k] = placed[k];
+            }
+        }
         // Residency classes.  One launch has one LDS size, and the largest trajectory of a batch would set it for all: at 128 lanes
         // a single 41 KB trajectory among 8192 pushes everybody from four workgroups per CU to three (-16 %).  Trajectories above
         // the residency limit therefore form a second class that is launched concurrently on a second stream with its own size.

@@ -48,6 +48,14 @@ class KinoAstar:
         self.slots = self.L.uph_kino_slots(self.h)
         self.n_primitives = self.L.uph_kino_primitives(self.h)
 
+    def set_wps(self, wps):
+        """experiment knob: waves per SIMD of the search kernel (2, 4, 6, 8)"""
+        _lib.check(self.L.uph_kino_set_wps(self.h, int(wps)), "uph_kino_set_wps")
+
+    def set_flags(self, flags):
+        """experiment knob: bit 0 dynamic query hand-out, bit 1 sincosFast (both on by default)"""
+        _lib.check(self.L.uph_kino_set_flags(self.h, int(flags)), "uph_kino_set_flags")
+
     def close(self):
         if getattr(self, "h", None):
             self.L.uph_kino_destroy(self.h)
