@@ -350,19 +350,46 @@ def main():
         # of the batch's first problems (same streams, same acceptance), one wave64 per query (csrc/kino_search.hip); the CPU restatement is timed
         # in the cpu_baseline leg below
         try:
-            fq = min(2048, args.batch)
+            fq = 65536 if args.batch >= 16384 else min(2048, args.batch)      # many queries per workspace: the shared cursor balances the launch's tail
             S_, G_ = scenes.random_queries(fq, seed0=1000, occ_r2=m.occ_r2_buffer, grid=gridinfo)
             ka = U.KinoAstar(m)
             ka.plan_batch(S_[:64], G_[:64], path_cap=1)
             fe = {"slots": ka.slots, "primitives": ka.n_primitives}
-            for nq in (1, 256, fq):
+            for nq in sorted(set((1, 256, min(fq, 2048), fq))):
                 t1 = time.perf_counter()
-                r_ = ka.plan_batch(S_[:nq], G_[:nq], path_cap=512)
+                r_ = ka.plan_batch(S_[:nq], G_[:nq], path_cap=64 if nq > 4096 else 512)
                 wall = time.perf_counter() - t1
                 fe["B%d" % nq] = {"queries_per_s": nq / wall, "ms_per_call": wall * 1e3, "kernel_ms": ka.stats()["kernel_ms"], "found": float(np.mean([q_["status"] == 0 for q_ in r_])),
                                   "expansions_per_query": float(np.mean([q_["iter_num"] for q_ in r_])), "M_expansions_per_s": float(np.sum([q_["iter_num"] for q_ in r_])) / wall / 1e6}
             extras["front_end"] = fe
             extras["_front_end_queries"] = (S_, G_)
+            # goal -> trajectory with every stage batched: search (device), PlanManager's resampling stage (uph_resample_batch, host C++), optimise
+            # (device) -- the reference's rcvWpsCallBack chain (plan_manager.cpp:56-134) for `pb` goals in one go; goals whose search fails are dropped
+            # as the reference drops them (empty front_end_path).  Wall clock of the three stages, results downloaded.
+            from uneven_planner_amd import resample as RS
+            pb = min(16384, fq)
+            t1 = time.perf_counter()
+            sr = ka.plan_batch(S_[:pb], G_[:pb], path_cap=768)
+            t2 = time.perf_counter()
+            search_kernel_s = ka.stats()["kernel_ms"] * 1e-3
+            paths = [q_["path"] for q_ in sr if q_["status"] == 0 and q_["n_path"] <= 768]
+            t2b = time.perf_counter()
+            pr_ = RS.resample_batch(paths)
+            t3 = time.perf_counter()
+            po = U.ALMTrajOpt(m)
+            po.set_rho(1.0)
+            prep = po.prepare_boundary(pr_)                       # (ctypes packing of the Python binding: a C++ host hands its arrays over as they are)
+            t3b = time.perf_counter()
+            pout = po.optimize_boundary(pr_, prepared=prep)
+            t4 = time.perf_counter()
+            native = search_kernel_s + (t3 - t2b) + po.last_boundary_s
+            extras["pipeline"] = {"goals": pb, "paths_found": len(paths), "search_kernel_s": search_kernel_s, "resample_s": t3 - t2b, "optimise_call_s": po.last_boundary_s,
+                                  "goals_per_s": pb / native, "trajectories_per_s": len(paths) / native, "python_binding_overhead_s": (t4 - t1) - native,
+                                  "converged_frac": float(np.mean([o_["ret"] == 0 for o_ in pout])), "mean_pieces": float(np.mean([p_["inner_xy"].shape[1] + 1 for p_ in pr_])),
+                                  "note": "KinoAstar::plan -> PlanManager resampling -> ALMTrajOpt::optimizeSE2Traj for a batch of goals: search kernel + uph_resample_batch (host C++) + "
+                                          "one uph_optimize_batch call (upload, initScaling, solve, download; first call of its context); the ctypes packing / unpacking of the Python "
+                                          "binding is reported separately"}
+            del po
             del ka
         except Exception as e:
             extras["front_end"] = {"error": repr(e)}
@@ -534,7 +561,8 @@ def main():
                 fdt = time.perf_counter() - t0
                 res["front_end"]["cpu"] = {"ms_per_goal": fdt * 1e3 / 64, "queries_per_s": 64 / fdt, "cores": 1, "kind": "port", "sample": "first 64 queries, CPU oracle (oracle/kino_astar.hpp), %.2f s" % fdt,
                                            "expansions_per_query": float(np.mean([q_["iter_num"] for q_ in fr])), "found": float(np.mean([q_["status"] == 0 for q_ in fr]))}
-                res["front_end"]["gpu_over_cpu_per_goal"] = res["front_end"]["B%d" % min(2048, args.batch)]["queries_per_s"] / (64 / fdt)
+                big = max(int(k_[1:]) for k_ in res["front_end"] if k_.startswith("B"))
+                res["front_end"]["gpu_over_cpu_per_goal"] = res["front_end"]["B%d" % big]["queries_per_s"] / (64 / fdt)
             if args.cpu_threads > 1 and not km2:
                 # context only: the reference is single-threaded; this is "one trajectory per host thread" on the same box
                 from concurrent.futures import ThreadPoolExecutor

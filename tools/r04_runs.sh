@@ -132,5 +132,23 @@ UPH_LANES=512 timeout 100 python tools/phase_breakdown.py 1 2>&1 | grep -E "cycl
 UPH_PB_ONLY_YAML=1 timeout 600 python tools/parity_buckets.py 1024 $OUT/parity_buckets_hill_1024.json hill > $OUT/parity_buckets_hill_1024.txt 2>&1
 tail -12 $OUT/parity_buckets_hill_1024.txt | cut -c1-700
 ;;
+7)
+# end-of-round check: build + smoke, the whole GPU tier, tools/profile.sh <tag> (bench line, kernel trace, counter passes, calibration)
+cd $GRAFT_REPO_ROOT
+TAG=${2:-r04p}
+export UPH_GIT_HEAD=$(cat build/git_head.txt 2>/dev/null || echo unknown)
+OUT=gpurun_out/final_$TAG; mkdir -p $OUT
+python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt | cut -c1-300
+timeout 900 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; tail -4 $OUT/gpu_tests.txt | cut -c1-300
+timeout 1200 bash tools/profile.sh $TAG 2>&1 | grep -E "uph_solver_kernel<128, 2, 2|FETCH_SIZE  |WRITE_SIZE  |SQ_INSTS_VALU|SQ_WAIT_ANY|SQ_WAVE_CYCLES|SQ_ACTIVE_INST_VALU" | head -14
+python - $TAG <<'PY'
+import json, sys
+r = json.loads(open("gpurun_out/prof_%s/bench.json" % sys.argv[1]).read().strip().split("\n")[-1])
+print(r["value"], r["ms_per_step"], r["roofline"]["frac"], r["roofline"]["avg_launch_ms"], r["penalty_kernel"]["batch"]["frac"], r["boundary"]["B%d" % r["config"]["batch_per_gpu"]], r.get("converged_traj_opts_per_s"))
+print("front_end", json.dumps(r.get("front_end"))[:900])
+print("drift", json.dumps(r.get("parity_floor", {}).get("drift")))
+print("map", r.get("map_build_s"), r.get("map_build_stages_ms"))
+PY
+;;
 *) echo "usage: tools/r04_runs.sh <n>";;
 esac
