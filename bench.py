@@ -204,6 +204,7 @@ def main():
     if args.single_process:
         return single_process(args)
     km2 = args.workload == "km2"
+    map_device_s = map_device_warm_s = map_download_s = None
     if not args.batch:
         args.batch = 4096 if km2 else 16384
 
@@ -238,10 +239,17 @@ def main():
     else:
         xyz = scenes.make_hill_cloud()      # hill cloud -> SE(2) grid by the plane-fit kernel
         m = U.UnevenMap(device=device)
+        t0 = time.time()
         if distributed and int(m.voxel_num[0]) % world == 0:
             m.build_sharded(xyz, rank, world, gather)
         else:
-            m.build(xyz)
+            m.build(xyz, download=False)    # uph_map_build: cloud upload, crop + voxel filter, bucketing, plane fits, commit -- all on the device
+            map_device_s = time.time() - t0
+            m.build(xyz, download=False)    # (second call: the build scratch exists)
+            map_device_warm_s = time.time() - t0 - map_device_s
+            td = time.time()
+            m.download()                    # host copies of map_buffer / c_buffer / occupancy for the untouched host consumers: 105 MB into fresh numpy arrays
+            map_download_s = time.time() - td
     map_build_s = time.time() - t0
     map_stats = m.build_stats()
 
@@ -482,6 +490,7 @@ def main():
             "lbfgs_iters_per_traj": iters / K / args.batch, "evals_per_traj": evals / K / args.batch,
             "scaling_kernel_ms": float(np.mean(prepare_ms)),
             "converged_frac": float((rets == 0).mean()), "map_build_s": map_build_s, "map_kernel_ms": map_stats["kernel_ms"],
+            "map_build_device_s": map_device_s, "map_build_device_warm_s": map_device_warm_s, "map_download_s": map_download_s,      # N = 1 hill: first / second uph_map_build call, then the D2H copy
             "map_build_stages_ms": map_stats.get("stages_ms"),      # rank 0's uph_map_build (its x-slab when N > 1): upload, crop + voxel, bucketing, kernel, commit, call; map_build_s adds the all-gather and the download into numpy
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "uph_solver_kernel<%s,2> (ALM/L-BFGS solve)" % ("128,2" if args.batch >= 2304 else ("256,2" if args.batch >= 512 else "256,1")), "avg_launch_ms": avg_ms,
