@@ -150,5 +150,39 @@ print("drift", json.dumps(r.get("parity_floor", {}).get("drift")))
 print("map", r.get("map_build_s"), r.get("map_build_stages_ms"))
 PY
 ;;
+8)
+# one wave per trajectory, eight workgroups per CU, on short problems; then the final bench line of HEAD
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r04g; mkdir -p $OUT
+timeout 400 python tools/single_wave_class.py 8192 2>&1 | grep -v amdgpu.ids | tee $OUT/single_wave_class.txt
+make -C oracle -s 2>&1 | tail -2
+timeout 400 python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?"; tail -c 400 $OUT/bench.json
+;;
+9)
+# single-wave forms (2)-(4) of profiles/r04h_single_wave_forms.txt: A/B on the bench batch (knob on / off), then the tests that depend on lane selection.
+# Needs tools/experiments/r04_paired_one_wave.patch applied (uph_ctx_set_single_wave is not in the shipped library).
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/${2:-r04h}; mkdir -p $OUT
+python - <<'PY' | tee $OUT/single_wave_ab.txt
+import time, numpy as np
+import uneven_planner_amd as U
+from uneven_planner_amd import scenes
+m = U.UnevenMap(); m.build(scenes.make_hill_cloud())
+nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
+probs = scenes.random_problems(16384, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
+for B in (16384, 8192):
+    for on in (0, 1, 0, 1):
+        o = U.ALMTrajOpt(m); o.set_single_wave(on); o.upload(probs[:B])
+        o.set_rho(1.0); o.solve()
+        ms = []
+        for _ in range(3):
+            o.set_rho(1.0); o.solve(); ms.append(o.stats()["kernel_ms"])
+        ln = o.lanes_per_problem(); r = np.array([q["ret"] for q in o.download(full=False)])
+        print("B %5d single_wave %d: solve kernel %.1f ms (%s) -> %.0f traj-opts/s by kernel time; one-wave share %.2f; converged %.3f; prepare %.1f ms" % (
+            B, on, np.mean(ms), ["%.1f" % v for v in ms], B / np.mean(ms) * 1e3, (ln == 64).mean(), (r == 0).mean(), o.stats()["prepare_ms"]))
+        del o
+PY
+timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_lanes.py tests/test_gpu_parity.py tests/test_gpu_edge.py -q 2>&1 | tail -8 | cut -c1-300 | tee $OUT/tests.txt
+;;
 *) echo "usage: tools/r04_runs.sh <n>";;
 esac
