@@ -123,3 +123,25 @@ def test_plan_is_the_reference_call(hill, oracle):
     opt = U.ALMTrajOpt(m)
     out = opt.optimize_batch([prob])[0]
     assert out["ret"] in (0, 2) and np.isfinite(out["cost"])
+
+
+@pytest.mark.parametrize("params", [dict(collision_interval=0.02),                      # 7 collision samples per primitive: each primitive's lane walks its samples itself
+                                    dict(time_interval=0.5, collision_interval=0.05),   # longer arcs, 5 samples (same generic layout)
+                                    dict(max_vel=0.8, max_steer=0.3, weight_v_change=0.5, weight_delta_change=0.3),      # other primitives, 4 samples
+                                    dict(collision_interval=0.08, oneshot_range=2.0)],  # one sample per primitive (the spread layout: end state + samples over four lane groups)
+                         ids=["7-samples", "long-arcs", "other-primitives", "1-sample"])
+def test_other_primitive_tables(hill, oracle, params):
+    """the kernel has two layouts of an expansion -- end state and collision samples of a primitive spread over lanes p, 16 + p, 32 + p, 48 + p
+    (<= 16 primitives of <= 3 samples, run_hill.yaml's case) or one lane per primitive walking its samples -- and hands stateTransit host-made
+    constants per (primitive, duration): other parameter sets exercise both against the oracle, expansion sequence included"""
+    import uneven_planner_amd as U
+    m, g = hill
+    ka = U.KinoAstar(m, params=params)
+    ok = oracle.OracleKinoAstar(g, params)
+    S, G = _queries(m, 6, 4700)
+    n_ok = 0
+    for d, s, gl in zip(ka.plan_batch(S, G, path_cap=1024, exp_cap=40000), S, G):
+        o = ok.plan(s, gl)
+        _same(d, o, str(params))
+        n_ok += o["status"] == 0
+    assert n_ok >= 3

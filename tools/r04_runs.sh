@@ -184,5 +184,13 @@ for B in (16384, 8192):
 PY
 timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_lanes.py tests/test_gpu_parity.py tests/test_gpu_edge.py -q 2>&1 | tail -8 | cut -c1-300 | tee $OUT/tests.txt
 ;;
+10)
+# front-end search kernel after a change: the four kino tests, then throughput at 2 and 4 waves per SIMD (every probe under its own timeout)
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/${2:-r04l}; mkdir -p $OUT
+make -C oracle -s 2>&1 | tail -2
+timeout 300 python -m pytest tests/test_gpu_kino.py -x -q 2>&1 | tail -6 | cut -c1-300 | tee $OUT/kino_tests.txt
+for w in 4 2; do timeout 150 python tools/kino_probe.py $w 3 ${3:-16384} 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kino_probe.txt; done
+;;
 *) echo "usage: tools/r04_runs.sh <n>";;
 esac

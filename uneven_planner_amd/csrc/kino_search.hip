@@ -63,9 +63,13 @@ constexpr int K_CLOSE = 'a', K_OPEN = 'b';
 struct KinoDev {
     double yaw_inv, lambda_heu, w_r2, w_so2, w_vch, w_dch, w_sigma, time_interval, coll_interval, oneshot_range, wheel_base, rho, tie_breaker;
     int n_inputs, nyawk, allocate_num, nxy;
+    int spread;                                    // 1: <= 16 primitives with <= 3 collision samples each -- end state and samples of a primitive go to lanes p, 16 + p, 32 + p, 48 + p
     double in_v[K_MAX_INPUTS], in_steer[K_MAX_INPUTS], in_tan[K_MAX_INPUTS];
     int in_nt[K_MAX_INPUTS];
     double in_t[K_MAX_INPUTS][K_MAX_TSAMP];
+    // stateTransit's per-(primitive, duration) constants, formed on the host by the reference's own operations (kino_astar.h:221-223):
+    // s = v T, y = s tan(delta) / wheel_base, r = s / y;  index 0 = the end state (T = time_interval), k + 1 = collision sample k
+    double in_s[K_MAX_INPUTS][K_MAX_TSAMP + 1], in_y[K_MAX_INPUTS][K_MAX_TSAMP + 1], in_r[K_MAX_INPUTS][K_MAX_TSAMP + 1];
 };
 
 struct __attribute__((aligned(64))) KNode {       // PathNode, kino_astar.h:34-46 (one 64-byte line)
@@ -103,6 +107,7 @@ __device__ __forceinline__ double klane(double v, int l) {      // l wave-unifor
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 __device__ __forceinline__ int klane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+template <int R> __device__ __forceinline__ int kRowRor(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + R, 0xf, 0xf, false); }      // row_ror:R inside each row of 16 lanes
 
 __device__ __forceinline__ int kFloorToInt(double v) {          // (int)floor(v) as x86-64 converts it
     const double f = floor(v);
@@ -115,7 +120,8 @@ __device__ __forceinline__ double kNormalizeAngle(double angle) {      // kino_a
     for (int it = 0; it < 4096 && a < -3.14159265358979323846; it++) a += 6.283185307179586;
     return a;
 }
-// kino_astar.h:218-240 with tan(delta) handed in (formed on the host) and sin / cos of the node's own heading (sw0, cw0: the same for every
+// kino_astar.h:218-240 with s, y = s tan(delta) / L and r = s / y handed in (constants of the primitive and the duration, formed on the host by the
+// same operations) and sin / cos of the node's own heading (sw0, cw0: the same for every
 // primitive and collision sample of an expansion) computed once; sincosFast: fdlibm kernels, < 0.8 ulp (uph_common.hpp)
 template <bool FAST>
 __device__ __forceinline__ void kSinCos(double x, double& sn, double& cs) {
@@ -123,12 +129,8 @@ __device__ __forceinline__ void kSinCos(double x, double& sn, double& cs) {
     else { sn = sin(x); cs = cos(x); }
 }
 template <bool FAST>
-__device__ __forceinline__ void kStateTransit(const KinoDev& P, double x0, double y0, double w0, double sw0, double cw0, double v, double delta, double tand, double T, double& x1, double& y1,
-                                              double& w1) {
-    const double s = v * T;
-    const double y = s * tand / P.wheel_base;
+__device__ __forceinline__ void kStateTransit(double x0, double y0, double w0, double sw0, double cw0, double delta, double s, double y, double r, double& x1, double& y1, double& w1) {
     if (fabs(delta) > 1e-4) {
-        const double r = s / y;
         double sw1, cw1;
         kSinCos<FAST>(w0 + y, sw1, cw1);
         x1 = x0 + r * (sw1 - sw0);
@@ -256,9 +258,20 @@ __device__ void kDubinsInterpolate(const KinoDev& P, const double from[3], const
 }
 
 // ---- open heap: libstdc++ __push_heap / __adjust_heap with comp(a, b) = a.f > b.f (NodeComparator, kino_astar.h:49-57)
+// The first TOPN positions (the top levels of the tree, which every pop walks and every push may reach) live in the wave's LDS, the rest in the
+// slot's HBM workspace: a pop of a 10 000-entry heap then has ~4 dependent HBM round trips instead of ~13.
+template <int TOPN>
+struct KHeapRef {
+    KHeap* top;      // LDS, positions [0, TOPN)
+    KHeap* glob;     // HBM, positions [TOPN, ...)  (indexed by position)
+    __device__ __forceinline__ KHeap get(int i) const { return i < TOPN ? top[i] : glob[i]; }
+    __device__ __forceinline__ void set(int i, const KHeap& e) const { if (i < TOPN) top[i] = e; else glob[i] = e; }
+    __device__ __forceinline__ void setF(int i, double f) const { if (i < TOPN) top[i].f = f; else glob[i].f = f; }
+};
 // push: the new leaf sits at position n; every ancestor is fetched at once (lane d holds the ancestor d levels up), the sift-up stops at the
 // first ancestor that is NOT greater than the value (NaN compares false: stops), the ancestors below move down one level each.
-__device__ __forceinline__ void kHeapPush(KHeap* heap, int* pos, int n, int id, double f, int lane) {
+template <int TOPN>
+__device__ __forceinline__ void kHeapPush(const KHeapRef<TOPN>& heap, int* pos, int n, int id, double f, int lane) {
     const int hole = n;
     int depth = 0;                                   // number of ancestors
     for (int h = hole; h > 0; h = (h - 1) >> 1) depth++;
@@ -267,32 +280,33 @@ __device__ __forceinline__ void kHeapPush(KHeap* heap, int* pos, int n, int id, 
     if (lane >= 1 && lane <= depth) {
         apos = ((hole + 1) >> lane) - 1;
         cpos = ((hole + 1) >> (lane - 1)) - 1;
-        anc = heap[apos];
+        anc = heap.get(apos);
     }
     const unsigned long long stop = __ballot(lane >= 1 && lane <= depth && !(anc.f > f));
     const int D = stop ? (int)__builtin_ctzll(stop) : depth + 1;      // first level that does not move
-    if (lane >= 1 && lane < D) { heap[cpos] = anc; pos[anc.id] = cpos; }
+    if (lane >= 1 && lane < D) { heap.set(cpos, anc); pos[anc.id] = cpos; }
     if (lane == 0) {
         const int fin = ((hole + 1) >> (D - 1)) - 1;
         KHeap e; e.f = f; e.id = id; e.pad = 0;
-        heap[fin] = e; pos[id] = fin;
+        heap.set(fin, e); pos[id] = fin;
     }
 }
 // pop of the root: value = last entry, __adjust_heap(first, 0, len = n - 1, value).  The sift-down always runs to a leaf (smaller-f child,
 // the right one when neither compares greater), then the value sifts up along that path.  With E_k the entry the path met at level k
 // (k = 1..L, positions p_k) the final layout is: heap[p_{k-1}] = E_k for k <= h, heap[p_h] = value, levels below h untouched, where h walks up
 // from L while E_h.f > value.f.  Lane k keeps (E_k, p_k, p_{k-1}); one dependent load pair per level.
-__device__ __forceinline__ void kHeapPop(KHeap* heap, int* pos, int n, int lane) {
+template <int TOPN>
+__device__ __forceinline__ void kHeapPop(const KHeapRef<TOPN>& heap, int* pos, int n, int lane) {
     if (n <= 1) return;
     const int len = n - 1;
-    KHeap value = heap[len];
+    KHeap value = heap.get(len);
     value.f = kuni(value.f); value.id = kuni(value.id);
     KHeap mine; mine.f = 0.0; mine.id = -1; mine.pad = 0;      // lane k: E_k
     int my_p = -1, my_pp = -1;                                   // p_k, p_{k-1}
     int hole = 0, second = 0, L = 0;
     while (second < (len - 1) / 2 && L < 60) {
         second = 2 * (second + 1);
-        const KHeap r = heap[second], l = heap[second - 1];      // (uniform addresses: one transaction each)
+        const KHeap r = heap.get(second), l = heap.get(second - 1);      // (uniform addresses: one transaction each)
         const double rf = kuni(r.f), lf = kuni(l.f);
         const bool takeLeft = rf > lf;                           // comp(first + second, first + (second - 1))
         if (takeLeft) second--;
@@ -302,7 +316,7 @@ __device__ __forceinline__ void kHeapPop(KHeap* heap, int* pos, int n, int lane)
     }
     if ((len & 1) == 0 && second == (len - 2) / 2) {
         second = 2 * (second + 1);
-        const KHeap l = heap[second - 1];
+        const KHeap l = heap.get(second - 1);
         L++;
         if (lane == L) { mine.f = kuni(l.f); mine.id = kuni(l.id); my_p = second - 1; my_pp = hole; }
         hole = second - 1;
@@ -312,9 +326,9 @@ __device__ __forceinline__ void kHeapPop(KHeap* heap, int* pos, int n, int lane)
     int h = 0;
     if (keep) h = 63 - (int)__builtin_clzll(keep);               // highest such level <= L
     // entries at levels <= h move up one level; levels > h stay where they were (they were never written)
-    if (lane >= 1 && lane <= h) { heap[my_pp] = mine; pos[mine.id] = my_pp; }
+    if (lane >= 1 && lane <= h) { heap.set(my_pp, mine); pos[mine.id] = my_pp; }
     const int ph = h == 0 ? 0 : klane(my_p, h);
-    if (lane == 0) { heap[ph] = value; pos[value.id] = ph; }
+    if (lane == 0) { heap.set(ph, value); pos[value.id] = ph; }
 }
 
 // ------------------------------------------------------------------------------------------------ the search kernel: one wave64 per query
@@ -323,16 +337,40 @@ __device__ __forceinline__ void kHeapPop(KHeap* heap, int* pos, int n, int lane)
 #endif
 // WPS = waves per SIMD the instantiation is compiled for (uph_kino_set_wps picks one: 2 = 256 registers, 4 = 128, 6 = 80, 8 = 64);
 // FAST = sincosFast (fdlibm kernels, uph_common.hpp) instead of the device library's sin / cos
+// -DUPH_KINO_PROF (tools/kino_phase_probe.py): shader-clock cycles per section of the expansion loop, left in the last two rows of the query's
+// path output (a profiling build only: those rows are then not poses)
+#ifdef UPH_KINO_PROF
+#define KPROF(k) do { const long long t_ = (long long)__builtin_readcyclecounter(); kprof[k] += t_ - kprof_t; kprof_t = t_; } while (0)
+#else
+#define KPROF(k) do { } while (0)
+#endif
 template <int WPS, bool FAST>
 __global__ __launch_bounds__(64, WPS) void uph_kino_kernel(GridDev g, const char* __restrict__ occ, const char* __restrict__ occ2, const KinoDev* __restrict__ Pp, KinoWork W, size_t node_stride,
                                                       size_t heap_stride, size_t table_stride, KinoIO io, int B) {
     const int lane = threadIdx.x;
     const KinoDev& P = *Pp;
     KNode* nodes = W.nodes + (size_t)blockIdx.x * node_stride;
-    KHeap* heap = W.heap + (size_t)blockIdx.x * heap_stride;
+    constexpr int TOPN = WPS <= 2 ? 1023 : (WPS <= 4 ? 511 : 255);      // 16 / 8 / 4 KB of LDS per wave: 8 / 16 / 24-32 waves per CU
+    __shared__ KHeap heap_top[TOPN];
+    const KHeapRef<TOPN> heap = {heap_top, W.heap + (size_t)blockIdx.x * heap_stride};
     int* pos = W.pos + (size_t)blockIdx.x * node_stride;
     int* nkey = W.key + (size_t)blockIdx.x * node_stride;
     int* table = W.table + (size_t)blockIdx.x * table_stride;
+    // This lane's primitive and its role, the same for every expansion of every query: with <= 16 primitives of <= 3 collision samples
+    // (run_hill.yaml: 15 of 2) the end state and the samples of primitive p -- independent evaluations of stateTransit -- go to lanes p, 16 + p,
+    // 32 + p, 48 + p and are formed in ONE pass, a ballot brings the samples' verdicts to the primitive's lane.  (The reference's loop stops at
+    // the first occupied sample and uses only "was one occupied": the same predicate.)  Otherwise the primitive's lane walks its samples itself.
+    const int plane = P.spread ? (lane & 15) : lane;             // this lane's primitive
+    const int sgrp = P.spread ? (lane >> 4) : 0;                 // 0: end state, k: collision sample k - 1
+    const bool pvalid = plane < P.n_inputs;
+    bool l_samp = false;
+    double l_iv = 0.0, l_is = 0.0, l_s = 0.0, l_y = 0.0, l_r = 0.0;      // the primitive's (v, delta) and stateTransit's constants for this lane's duration
+    if (pvalid) {
+        l_samp = P.spread && sgrp > 0 && sgrp - 1 < P.in_nt[plane];
+        const int ti = l_samp ? sgrp : 0;
+        l_iv = P.in_v[plane]; l_is = P.in_steer[plane];
+        l_s = P.in_s[plane][ti]; l_y = P.in_y[plane][ti]; l_r = P.in_r[plane][ti];
+    }
     // queries are handed out dynamically, longest (by straight-line distance) first: io.order is that order, io.next the shared cursor
     // (io.next == nullptr: static assignment, query blockIdx.x + k gridDim.x of the order)
     for (int turn = 0; turn <= B; turn++) {                       // (a wave can take at most B queries: the bound is a guard)
@@ -347,6 +385,9 @@ __global__ __launch_bounds__(64, WPS) void uph_kino_kernel(GridDev g, const char
         const double sx0 = io.starts[3 * q], sy0 = io.starts[3 * q + 1], sw0 = io.starts[3 * q + 2];
         const double gx = io.goals[3 * q], gy = io.goals[3 * q + 1], gw = io.goals[3 * q + 2];
         int status = -1, iter_num = 0, use_node_num = 0, n = 0, n_path = 0;
+#ifdef UPH_KINO_PROF
+        long long kprof[6] = {0, 0, 0, 0, 0, 0}, kprof_t = (long long)__builtin_readcyclecounter();
+#endif
         if (kOcc(g, occ, sx0, sy0, sw0) == 1) status = 1;                                  // kino_astar.cpp:86-90
         else if (kOccXY(g, occ2, gx, gy, gw) == 1) status = 2;                             // :91-95
         if (status < 0) {
@@ -373,7 +414,8 @@ __global__ __launch_bounds__(64, WPS) void uph_kino_kernel(GridDev g, const char
         while (status < 0) {
             if (n == 0) { status = 3; break; }                                             // :111, :233
             if (iter_num > 2 * P.allocate_num) { status = 6; break; }                      // (cannot happen: every pop consumes a push and pushes stop at allocate_num -- a guard, not a rule)
-            const int cur = kuni(heap[0].id);
+            KPROF(5);
+            const int cur = kuni(heap_top[0].id);
             const KNode cn = nodes[cur];
             const double cx = kuni(cn.sx), cy = kuni(cn.sy), cw = kuni(cn.syaw), cg = kuni(cn.g), civ = kuni(cn.in_v), cis = kuni(cn.in_steer);
             {
@@ -420,7 +462,30 @@ __global__ __launch_bounds__(64, WPS) void uph_kino_kernel(GridDev g, const char
                     }
                 }
             }
+            // ---- the primitives of this node, one per lane (:147-195), in two stages around the pop.  Nothing they read is written by the pop
+            // (heap and pos only), so the loads of stage 0 -- table rows, occupancy of the collision samples -- are in flight while the pop
+            // walks the heap; stage 1 (the nodes found in the table, the terrain lookup) follows it.
+            KPROF(0);                                                                      // 0: top of the heap, node fetch, one-shot test
+            double csw, ccw;
+            kSinCos<FAST>(cw, csw, ccw);
+            bool act = false;
+            double px = 0.0, py = 0.0, pw = 0.0, tg = 0.0, tf = 0.0, iv = 0.0, is = 0.0;
+            int key = -1, pre = -1, pre_flag = 0;
+            double pre_g = 0.0;
+            iv = l_iv; is = l_is;
+            int occ_samp = 0;                                        // spread form: this lane's collision sample (1 = occupied)
+            bool inmap = false;
+            if (pvalid) kStateTransit<FAST>(cx, cy, cw, csw, ccw, is, l_s, l_y, l_r, px, py, pw);
+            if (l_samp) occ_samp = kOccXY(g, occ2, px, py, pw);
+            if (pvalid && sgrp == 0 && isInMap<double>(g, px, py, pw)) {                   // :154-158
+                int id3[3];
+                inmap = true;
+                key = kKey(g, P, px, py, pw, id3);
+                pre = key >= 0 ? table[key] : -1;                                          // :163-164
+            }
+            KPROF(1);                                                                      // 1: stage 0 (state transit, keys; loads issued)
             kHeapPop(heap, pos, n, lane);                                                  // :129-131
+            KPROF(2);                                                                      // 2: pop
             n--;
             if (lane == 0) nodes[cur].flag = K_CLOSE;
             if (io.expanded && iter_num < io.exp_cap && lane == 0) {
@@ -432,50 +497,112 @@ __global__ __launch_bounds__(64, WPS) void uph_kino_kernel(GridDev g, const char
             }
             iter_num++;
             if (io.max_expand > 0 && iter_num >= io.max_expand) { status = 5; break; }
-            // ---- the primitives of this node, one per lane (:147-195)
-            double csw, ccw;
-            kSinCos<FAST>(cw, csw, ccw);
-            bool act = false;
-            double px = 0.0, py = 0.0, pw = 0.0, tg = 0.0, tf = 0.0, iv = 0.0, is = 0.0;
-            int key = -1, pre = -1, pre_flag = 0;
-            double pre_g = 0.0;
-            if (lane < P.n_inputs) {
-                iv = P.in_v[lane]; is = P.in_steer[lane];
-                const double tand = P.in_tan[lane];
-                kStateTransit<FAST>(P, cx, cy, cw, csw, ccw, iv, is, tand, P.time_interval, px, py, pw);
-                if (isInMap<double>(g, px, py, pw)) {                                      // :154-158
-                    int id3[3];
-                    key = kKey(g, P, px, py, pw, id3);
-                    pre = key >= 0 ? table[key] : -1;                                      // :163-164
-                    if (pre >= 0) { pre_flag = nodes[pre].flag; pre_g = nodes[pre].g; }
-                    bool closed = pre >= 0 && pre_flag == K_CLOSE;                         // :166-169
-                    int occv = 0;
+            const unsigned long long occ_any = __ballot(occ_samp == 1);     // bit 16 k + p: sample k - 1 of primitive p is occupied (spread form)
+            if (inmap) {
+                if (pre >= 0) { pre_flag = pre == cur ? K_CLOSE : nodes[pre].flag; pre_g = nodes[pre].g; }      // (cur was closed above)
+                bool closed = pre >= 0 && pre_flag == K_CLOSE;                             // :166-169
+                bool blocked = false;
+                if (P.spread) blocked = (((occ_any >> (16 + plane)) | (occ_any >> (32 + plane)) | (occ_any >> (48 + plane))) & 1ull) != 0;
+                else {
                     const int nt = P.in_nt[lane];
                     for (int s = 0; s < nt && !closed; s++) {                              // :171-185
                         double xt, yt, wt;
-                        kStateTransit<FAST>(P, cx, cy, cw, csw, ccw, iv, is, tand, P.in_t[lane][s], xt, yt, wt);
-                        occv = kOccXY(g, occ2, xt, yt, wt);
-                        if (occv == 1) break;
+                        kStateTransit<FAST>(cx, cy, cw, csw, ccw, is, P.in_s[lane][s + 1], P.in_y[lane][s + 1], P.in_r[lane][s + 1], xt, yt, wt);
+                        if (kOccXY(g, occ2, xt, yt, wt) == 1) { blocked = true; break; }
                     }
-                    if (!closed && occv != 1) {
-                        const double arc = iv * P.time_interval;
-                        double t = 0.0;                                                    // :187-195
-                        t += P.w_r2 * arc;
-                        t += P.w_so2 * fabs(is) * arc;
-                        t += P.w_vch * fabs(iv - civ);
-                        t += P.w_dch * fabs(is - cis);
-                        t += P.w_sigma * kTerrainSig(g, px, py, pw);
-                        t += cg;
-                        tg = t;
-                        const double dx = px - gx, dy = py - gy;
-                        tf = tg + P.lambda_heu * (P.tie_breaker * sqrt(dx * dx + dy * dy));
-                        act = true;
+                }
+                if (!closed && !blocked) {
+                    const double arc = iv * P.time_interval;
+                    double t = 0.0;                                                        // :187-195
+                    t += P.w_r2 * arc;
+                    t += P.w_so2 * fabs(is) * arc;
+                    t += P.w_vch * fabs(iv - civ);
+                    t += P.w_dch * fabs(is - cis);
+                    t += P.w_sigma * kTerrainSig(g, px, py, pw);
+                    t += cg;
+                    tg = t;
+                    const double dx = px - gx, dy = py - gy;
+                    tf = tg + P.lambda_heu * (P.tie_breaker * sqrt(dx * dx + dy * dy));
+                    act = true;
+                }
+            }
+            // ---- the primitives meet the table in their order (:197-229).  What each one finds there depends only on the EARLIER primitives of this
+            // expansion with the same key: the first of them creates the node unless the table held one, every later one relaxes it iff its g is
+            // below the running g.  Every lane replays that for its own key (one pass over the active lanes), so the actions -- NEW (with the pool
+            // index the sequential order would hand out), RELAX, nothing -- are known at once, the node records are written in parallel (the last
+            // writer of a key only), and the heap operations, whose order matters, follow in primitive order: push for NEW, the in-place key
+            // change for RELAX (no re-heapify, as the reference).
+            KPROF(3);                                                                      // 3: stage 1 (table nodes, terrain, cost)
+            unsigned long long todo = __ballot(act);
+            if (__ballot(act && key < 0)) { status = 6; break; }
+            bool exists = pre >= 0;
+            double gcur = pre_g;
+            int first_new = -1;
+            if (P.spread) {
+                // the primitives sit in lanes 0..15, one DPP row: fifteen row rotations show every lane every other one.  Of the EARLIER active
+                // lanes with its key a lane needs the first (it creates the node when the table had none) and the running g after all of them:
+                // g0 = the table node's g or the creator's, then g = g_i wherever g_i < g -- i.e. NaN if g0 is NaN, else the smallest of g0 and
+                // the members' non-NaN g.  Both are order-free (a minimum of lane indices, a NaN-ignoring minimum), so the rotation order is too.
+                const int actlane = act ? lane : -1;
+                const int tg_hi = __double2hiint(tg), tg_lo = __double2loint(tg);
+                int first_idx = 64, nearlier = 0;
+                double m_all = __longlong_as_double(0x7ff0000000000000ll);
+#define UPH_KSTEP(R)                                                                                                             \
+                {                                                                                                                \
+                    const int ol = kRowRor<R>(actlane), ok = kRowRor<R>(key);                                                    \
+                    const double og = __hiloint2double(kRowRor<R>(tg_hi), kRowRor<R>(tg_lo));                                    \
+                    if (act && ol >= 0 && ol < lane && ok == key) {                                                              \
+                        nearlier++;                                                                                              \
+                        if (ol < first_idx) first_idx = ol;                                                                      \
+                        if (og < m_all) m_all = og;                                                                              \
+                    }                                                                                                            \
+                }
+                UPH_KSTEP(1) UPH_KSTEP(2) UPH_KSTEP(3) UPH_KSTEP(4) UPH_KSTEP(5) UPH_KSTEP(6) UPH_KSTEP(7) UPH_KSTEP(8)
+                UPH_KSTEP(9) UPH_KSTEP(10) UPH_KSTEP(11) UPH_KSTEP(12) UPH_KSTEP(13) UPH_KSTEP(14) UPH_KSTEP(15)
+#undef UPH_KSTEP
+                const double gfirst = __shfl(tg, first_idx & 63);
+                if (pre >= 0) gcur = isnan(pre_g) ? pre_g : (m_all < pre_g ? m_all : pre_g);
+                else if (nearlier > 0) { exists = true; first_new = first_idx; gcur = isnan(gfirst) ? gfirst : (m_all < gfirst ? m_all : gfirst); }
+            } else {
+                for (unsigned long long m = todo; m; m &= m - 1) {
+                    const int i = (int)__builtin_ctzll(m);
+                    const int ki = klane(key, i);
+                    const double gi = klane(tg, i);
+                    if (act && ki == key && i < lane) {
+                        if (!exists) { exists = true; gcur = gi; first_new = i; }
+                        else if (gi < gcur) gcur = gi;
                     }
                 }
             }
-            // ---- the primitives meet the table in their order (:197-229).  A primitive whose key an EARLIER primitive of this expansion has
-            // inserted or relaxed re-reads the table; the others use what their lane fetched above.
-            unsigned long long todo = __ballot(act);
+            KPROF(4);                                                                      // 4: replay of the table order
+            const bool is_new = act && !exists, is_relax = act && exists && tg < gcur;
+            const unsigned long long newmask = __ballot(is_new), wmask = __ballot(is_new || is_relax);
+            const int n_new = __popcll(newmask);
+            if (use_node_num + n_new < P.allocate_num) {
+                const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+                int mypn = pre;
+                if (is_new) mypn = use_node_num + __popcll(newmask & below);
+                else if (first_new >= 0) mypn = use_node_num + __popcll(newmask & ((1ull << first_new) - 1ull));
+                if (is_new) { nkey[mypn] = key; table[key] = mypn; }
+                const bool iswr = is_new || is_relax;
+                for (unsigned long long m = wmask; m; m &= m - 1) {
+                    const int i = (int)__builtin_ctzll(m);
+                    const int pn = klane(mypn, i), ki = klane(key, i);
+                    const double ifs = klane(tf, i);
+                    // the node record: the LAST writer of a key leaves its state there (an earlier one's would be overwritten at once)
+                    const bool later = __ballot(iswr && key == ki && lane > i) != 0;
+                    if (!later && lane == i) {
+                        KNode nd;
+                        nd.sx = px; nd.sy = py; nd.syaw = pw; nd.g = tg; nd.f = tf; nd.in_v = iv; nd.in_steer = is; nd.parent = cur; nd.flag = K_OPEN;
+                        nodes[mypn] = nd;
+                    }
+                    if ((newmask >> i) & 1ull) { kHeapPush(heap, pos, n, pn, ifs, lane); n++; }
+                    else if (lane == 0) heap.setF(pos[pn], ifs);
+                }
+                use_node_num += n_new;
+                continue;
+            }
+            // the pool runs out inside this expansion (:212-216): one primitive at a time, as the reference, up to the one that takes the last node
             unsigned long long done = 0;
             while (todo) {
                 const int i = (int)__builtin_ctzll(todo);
@@ -505,13 +632,19 @@ __global__ __launch_bounds__(64, WPS) void uph_kino_kernel(GridDev g, const char
                     if (ig < pg) {
                         if (lane == 0) {
                             nodes[pn] = nd;
-                            heap[pos[pn]].f = ifs;                                         // the key the comparisons see from now on; no re-heapify (as the reference)
+                            heap.setF(pos[pn], ifs);                                       // the key the comparisons see from now on; no re-heapify (as the reference)
                         }
                         done |= 1ull << i;
                     }
                 }
             }
         }
+#ifdef UPH_KINO_PROF
+        if (lane == 0 && io.path_cap >= 2) {
+            double* pr = io.paths + ((size_t)q * io.path_cap + io.path_cap - 2) * 3;
+            for (int k = 0; k < 6; k++) pr[k] = (double)kprof[k];
+        }
+#endif
         if (lane == 0) { io.status[q] = status; io.n_path[q] = n_path; io.iter_num[q] = iter_num; io.use_node_num[q] = use_node_num; }
     }
 }
@@ -571,9 +704,20 @@ int uph_kino_create(uph_map* m, const uph_kino_params* kp, int32_t slots, uph_ki
                 P.in_t[ni][nt++] = t;
             }
             P.in_nt[ni] = nt;
+            for (int q = 0; q <= nt; q++) {
+                const double T = q == 0 ? kp->time_interval : P.in_t[ni][q - 1];
+                const double s_ = v * T;
+                const double y_ = s_ * P.in_tan[ni] / kp->wheel_base;
+                P.in_s[ni][q] = s_; P.in_y[ni][q] = y_; P.in_r[ni][q] = s_ / y_;
+            }
             ni++;
         }
     P.n_inputs = ni;
+    {
+        int mx = 0;
+        for (int i = 0; i < ni; i++) mx = std::max(mx, P.in_nt[i]);
+        P.spread = (ni <= 16 && mx <= 3) ? 1 : 0;
+    }
     if (slots == 0) {
         hipDeviceProp_t prop;
         KHIPCHK(hipGetDeviceProperties(&prop, k->device));
