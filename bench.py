@@ -390,13 +390,17 @@ def main():
             t3b = time.perf_counter()
             pout = po.optimize_boundary(pr_, prepared=prep)
             t4 = time.perf_counter()
+            first_call_s = po.last_boundary_s
+            po.set_rho(1.0)
+            po.optimize_boundary(pr_, prepared=prep)              # the same call again: device buffers and MINCO operators of this context exist now
             native = search_kernel_s + (t3 - t2b) + po.last_boundary_s
             extras["pipeline"] = {"goals": pb, "paths_found": len(paths), "search_kernel_s": search_kernel_s, "resample_s": t3 - t2b, "optimise_call_s": po.last_boundary_s,
-                                  "goals_per_s": pb / native, "trajectories_per_s": len(paths) / native, "python_binding_overhead_s": (t4 - t1) - native,
+                                  "optimise_first_call_s": first_call_s,
+                                  "goals_per_s": pb / native, "trajectories_per_s": len(paths) / native, "python_binding_overhead_s": (t4 - t1) - (search_kernel_s + (t3 - t2b) + first_call_s),
                                   "converged_frac": float(np.mean([o_["ret"] == 0 for o_ in pout])), "mean_pieces": float(np.mean([p_["inner_xy"].shape[1] + 1 for p_ in pr_])),
                                   "note": "KinoAstar::plan -> PlanManager resampling -> ALMTrajOpt::optimizeSE2Traj for a batch of goals: search kernel + uph_resample_batch (host C++) + "
-                                          "one uph_optimize_batch call (upload, initScaling, solve, download; first call of its context); the ctypes packing / unpacking of the Python "
-                                          "binding is reported separately"}
+                                          "one uph_optimize_batch call (upload, initScaling, solve, download; the second call of its context -- the first one, which also allocates the "
+                                          "device buffers and builds the MINCO operators, is optimise_first_call_s); the ctypes packing / unpacking of the Python binding is reported separately"}
             del po
             del ka
         except Exception as e:
