@@ -64,9 +64,8 @@ struct KinoDev {
     double yaw_inv, lambda_heu, w_r2, w_so2, w_vch, w_dch, w_sigma, time_interval, coll_interval, oneshot_range, wheel_base, rho, tie_breaker;
     int n_inputs, nyawk, allocate_num, nxy;
     int spread;                                    // 1: <= 16 primitives with <= 3 collision samples each -- end state and samples of a primitive go to lanes p, 16 + p, 32 + p, 48 + p
-    double in_v[K_MAX_INPUTS], in_steer[K_MAX_INPUTS], in_tan[K_MAX_INPUTS];
+    double in_v[K_MAX_INPUTS], in_steer[K_MAX_INPUTS];
     int in_nt[K_MAX_INPUTS];
-    double in_t[K_MAX_INPUTS][K_MAX_TSAMP];
     // stateTransit's per-(primitive, duration) constants, formed on the host by the reference's own operations (kino_astar.h:221-223):
     // s = v T, y = s tan(delta) / wheel_base, r = s / y;  index 0 = the end state (T = time_interval), k + 1 = collision sample k
     double in_s[K_MAX_INPUTS][K_MAX_TSAMP + 1], in_y[K_MAX_INPUTS][K_MAX_TSAMP + 1], in_r[K_MAX_INPUTS][K_MAX_TSAMP + 1];
@@ -695,19 +694,21 @@ int uph_kino_create(uph_map* m, const uph_kino_params* kp, int32_t slots, uph_ki
     for (double v = 0; v <= kp->max_vel + 1e-3; v += 0.5 * kp->max_vel)
         for (double steer = -kp->max_steer; steer <= kp->max_steer + 1e-3; steer += 0.5 * kp->max_steer) {
             if (ni >= K_MAX_INPUTS) { delete k; setError("uph_kino_create: more than 64 motion primitives"); return UPH_ERR_LIMIT; }
-            P.in_v[ni] = v; P.in_steer[ni] = steer; P.in_tan[ni] = std::tan(steer);
+            P.in_v[ni] = v; P.in_steer[ni] = steer;
+            const double tand = std::tan(steer);
+            double tsamp[K_MAX_TSAMP];
             const double arc = v * kp->time_interval;
             const double temp_ct = kp->collision_interval / arc * kp->time_interval;
             int nt = 0;
             for (double t = temp_ct; t <= kp->time_interval + 1e-3; t += temp_ct) {
                 if (nt >= K_MAX_TSAMP) { delete k; setError("uph_kino_create: more than 8 collision samples per primitive (collision_interval too fine)"); return UPH_ERR_LIMIT; }
-                P.in_t[ni][nt++] = t;
+                tsamp[nt++] = t;
             }
             P.in_nt[ni] = nt;
             for (int q = 0; q <= nt; q++) {
-                const double T = q == 0 ? kp->time_interval : P.in_t[ni][q - 1];
+                const double T = q == 0 ? kp->time_interval : tsamp[q - 1];
                 const double s_ = v * T;
-                const double y_ = s_ * P.in_tan[ni] / kp->wheel_base;
+                const double y_ = s_ * tand / kp->wheel_base;
                 P.in_s[ni][q] = s_; P.in_y[ni][q] = y_; P.in_r[ni][q] = s_ / y_;
             }
             ni++;
