@@ -471,10 +471,21 @@ def main():
         # the bound that actually binds: VALU issue.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over all waves; per SIMD
         # (4 per CU, 256 CUs) and per launch of the committed pass, against that pass's own launch duration at the 2.4 GHz shader clock
         valu_busy = wait_frac = None
+        mfma = None
         if pc is not None and pc.get("sq_active_inst_valu") and pc.get("launch_ms"):
             simd_cycles = 256 * 4 * pc["launch_ms"] * 1e-3 * 2.4e9
             valu_busy = pc["sq_active_inst_valu"] * 4.0 / max(1, pc["launches"]) / simd_cycles
             wait_frac = pc["sq_wait_any"] / pc["sq_wave_cycles"] if pc.get("sq_wave_cycles") else None
+            if pc.get("sq_insts_valu_mfma_f64"):
+                # north_star: "(where used) MFMA utilisation reported from rocprof against gfx950 peak".  The one matrix-core contraction of the path is the
+                # xy half of the gradient scatter (v_mfma_f64_16x16x4_f64: 2048 flop, 64 cycles per instruction = 32 flop/clk/SIMD, tools/micro/mfma_f64_probe.hip)
+                mf = pc["sq_insts_valu_mfma_f64"] / max(1, pc["launches"]) * 2048.0
+                mfma = {"insts_per_launch": pc["sq_insts_valu_mfma_f64"] / max(1, pc["launches"]), "instruction": "v_mfma_f64_16x16x4_f64", "achieved": mf / (pc["launch_ms"] * 1e-3) / 1e12,
+                        "peak": 32.0 * 1024 * 2.4e9 / 1e12, "unit": "TFLOP/s",
+                        "util": mf / (pc["launch_ms"] * 1e-3) / (32.0 * 1024 * 2.4e9),
+                        "busy_frac_of_simd_cycles": (pc.get("sq_valu_mfma_busy_cycles", 0.0) / max(1, pc["launches"])) / simd_cycles,
+                        "note": "fp64 matrix-core peak = 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz = 78.6 TFLOP/s (measured issue rate of the instruction); the path is not a GEMM -- the "
+                                "matrix cores carry the one shared-operand dense contraction it contains (DESIGN.md 7b)"}
         # 7 of the 47 doubles per sample are the residual stores of SURVEY.md 8d's definition, which the solve kernel performs once per L-BFGS
         # pass, not per evaluation: the fraction without them is reported next to the defined one
         moved_bytes = (sample_evals * (bytes_per_sample - 7 * 8) + hist_bytes + iters * 2 * 8 * (n_sum / max(1, args.batch))) / K
@@ -500,7 +511,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "uph_solver_kernel<%s,2> (ALM/L-BFGS solve)" % ("128,2" if args.batch >= 2304 else ("256,2" if args.batch >= 512 else "256,1")), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "frac_without_unwritten_residuals": moved_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "sample_bytes_per_launch": sample_evals * bytes_per_sample / K, "history_bytes_per_launch": hist_bytes / K,
-                         "valu_busy": valu_busy, "wave_wait_frac": wait_frac,
+                         "valu_busy": valu_busy, "wave_wait_frac": wait_frac, "mfma": mfma,
                          "valu_busy_source": ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch x 2.4 GHz) of the committed counter pass %s (git %s, kernel sources %s, launch %.1f ms)" % (
                              pc.get("tag"), pc.get("git_head"), pc.get("kernel_src_sha"), pc.get("launch_ms", float("nan")))) if pc is not None else pc_why,
                          "kernel_src_sha": kernel_sources_sha()},

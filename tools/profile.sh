@@ -50,6 +50,7 @@ pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum
 pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_VALU
+pmc mfma SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES
 # calibration: counted vs requested bytes on known patterns
 rm -f $OUT/fetch_calibration.txt
 for pat in gather8 rows16 stream16 stream8 write8; do
@@ -83,6 +84,7 @@ try: head = subprocess.check_output(['git', '-C', os.environ['GRAFT_REPO_ROOT'],
 except Exception: head = os.environ.get('UPH_GIT_HEAD', 'unknown (the GPU box holds a snapshot without .git)')
 json.dump({'batch': B, 'tag': 'profiles/%s_pmc_summary.txt' % os.path.basename(out).replace('prof_', ''), 'fetch_kib': vals.get('FETCH_SIZE', 0.0), 'write_kib': vals.get('WRITE_SIZE', 0.0), 'launches': 1,
            'sq_active_inst_valu': vals.get('SQ_ACTIVE_INST_VALU', 0.0), 'sq_wave_cycles': vals.get('SQ_WAVE_CYCLES', 0.0), 'sq_wait_any': vals.get('SQ_WAIT_ANY', 0.0), 'sq_insts_valu': vals.get('SQ_INSTS_VALU', 0.0),
+           'sq_insts_valu_mfma_f64': vals.get('SQ_INSTS_VALU_MFMA_F64', 0.0), 'sq_insts_valu_mfma_mops_f64': vals.get('SQ_INSTS_VALU_MFMA_MOPS_F64', 0.0), 'sq_valu_mfma_busy_cycles': vals.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0),
            'launch_ms': line['roofline']['avg_launch_ms'], 'kernel_src_sha': bench.kernel_sources_sha(), 'git_head': head,
            'note': 'ALM/L-BFGS solve kernel (uph_solver_kernel<*,2,2>), one launch of bench.py --steps 1 --warmup 0 (default batch); rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; see <tag>_fetch_calibration.txt for counted/requested on known patterns'},
           open(out + '/pmc_traffic.json', 'w'), indent=1)
