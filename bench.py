@@ -358,6 +358,8 @@ def main():
         # of the batch's first problems (same streams, same acceptance), one wave64 per query (csrc/kino_search.hip); the CPU restatement is timed
         # in the cpu_baseline leg below
         try:
+            if world > 1:
+                raise RuntimeError("single-GPU measurement: skipped when the job spans several GPUs (run `python bench.py` for it)")
             fq = 65536 if args.batch >= 16384 else min(2048, args.batch)      # many queries per workspace: the shared cursor balances the launch's tail
             S_, G_ = scenes.random_queries(fq, seed0=1000, occ_r2=m.occ_r2_buffer, grid=gridinfo)
             ka = U.KinoAstar(m)
