@@ -145,3 +145,19 @@ def test_other_primitive_tables(hill, oracle, params):
         _same(d, o, str(params))
         n_ok += o["status"] == 0
     assert n_ok >= 3
+
+
+def test_every_kernel_instantiation(hill, oracle):
+    """the search kernel is compiled per register budget (2 / 4 / 6 / 8 waves per SIMD: 1023 / 511 / 255 heap entries in LDS) and with or without
+    sincosFast; static or dynamic query hand-out is a run-time flag: every combination pops the oracle's sequence"""
+    import uneven_planner_amd as U
+    m, g = hill
+    ok = oracle.OracleKinoAstar(g)
+    S, G = _queries(m, 5, 4900)
+    ref = [ok.plan(s, gl) for s, gl in zip(S, G)]
+    ka = U.KinoAstar(m, slots=3)                       # fewer workspaces than queries: slots are reused inside the launch
+    for wps in (2, 4, 6, 8):
+        for flags in (0, 1, 2, 3):
+            ka.set_wps(wps); ka.set_flags(flags)
+            for d, o in zip(ka.plan_batch(S, G, path_cap=1024, exp_cap=40000), ref):
+                _same(d, o, "wps %d flags %d" % (wps, flags))
