@@ -272,8 +272,7 @@ struct KHeapRef {
 template <int TOPN>
 __device__ __forceinline__ void kHeapPush(const KHeapRef<TOPN>& heap, int* pos, int n, int id, double f, int lane) {
     const int hole = n;
-    int depth = 0;                                   // number of ancestors
-    for (int h = hole; h > 0; h = (h - 1) >> 1) depth++;
+    const int depth = 31 - __builtin_clz((unsigned)hole + 1u);      // number of ancestors = level of the leaf
     KHeap anc; anc.f = 0.0; anc.id = -1; anc.pad = 0;
     int apos = -1, cpos = -1;                        // position of this lane's ancestor and of the child on the path below it
     if (lane >= 1 && lane <= depth) {
