@@ -150,3 +150,54 @@ def test_occupied_start_or_goal_is_refused(oracle, analytic_cells):
     assert ka.plan([1.02, 1.02, 0.0], [3.0, 3.0, 0.0])["status"] == 1
     assert ka.plan([3.0, 3.0, 0.0], [1.02, 1.02, 0.0])["status"] == 2
     assert ka.plan([3.0, 3.0, 0.0], [0.0, 0.0, 0.0])["status"] == 0
+
+
+def test_table_replay_formula_equals_the_sequential_order():
+    """csrc/kino_search.hip lets every primitive of an expansion work out for itself what it will find in the lattice table when its turn comes
+    (kino_astar.cpp:197-229 processes them one after the other): of the EARLIER active primitives with its key the first creates the node unless the
+    table had one, and the node's g afterwards is g0 -- the table node's or the creator's -- lowered by every later member with g_i < g.  The kernel
+    evaluates that order-free (smallest lane; NaN if g0 is NaN, else the minimum of g0 and the members' non-NaN g) over DPP rotations.  Here: the
+    order-free form against the literal sequential loop on random expansions with duplicate keys, existing nodes and NaN costs."""
+    rng = np.random.default_rng(5)
+    nan = float("nan")
+    for trial in range(4000):
+        L = 16
+        keys = rng.integers(0, 5, L)
+        act = rng.random(L) < 0.7
+        tg = rng.choice([0.5, 1.0, 1.5, 2.0, 2.5, nan], L, p=[0.19, 0.19, 0.19, 0.19, 0.19, 0.05])
+        table = {int(k): (float(rng.choice([0.7, 1.2, 1.9, nan], p=[0.3, 0.3, 0.3, 0.1])) if rng.random() < 0.4 else None) for k in range(5)}
+        # the reference's order: one primitive after the other
+        seq = []
+        g_now = dict(table)
+        for i in range(L):
+            if not act[i]:
+                seq.append("none"); continue
+            k = int(keys[i])
+            if g_now[k] is None:
+                g_now[k] = float(tg[i]); seq.append("new")
+            elif tg[i] < g_now[k]:
+                g_now[k] = float(tg[i]); seq.append("relax")
+            else:
+                seq.append("none")
+        # the kernel's form, every lane on its own
+        par = []
+        for j in range(L):
+            if not act[j]:
+                par.append("none"); continue
+            k = int(keys[j])
+            earlier = [i for i in range(j) if act[i] and keys[i] == k]
+            m_all = float("inf")
+            for i in earlier:                       # (any order)
+                if tg[i] < m_all:
+                    m_all = float(tg[i])
+            if table[k] is not None:
+                g0 = table[k]; exists = True
+            elif earlier:
+                g0 = float(tg[min(earlier)]); exists = True
+            else:
+                g0 = None; exists = False
+            if not exists:
+                par.append("new"); continue
+            gcur = g0 if g0 != g0 else (m_all if m_all < g0 else g0)
+            par.append("relax" if tg[j] < gcur else "none")
+        assert par == seq, (trial, keys, act, tg, table, seq, par)
