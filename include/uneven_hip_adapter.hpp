@@ -188,6 +188,37 @@ inline void fillSE2TrajMsg(const SE2Trajectory& traj, Msg& msg) {
     }
 }
 
+// rosparam uneven_map/... as UnevenMap::init reads it (uneven_map/src/uneven_map.cpp:75-88; getParam: absent keys keep the value passed in,
+// which starts as run_hill.yaml:2-14) -- for hosts that create the device grid without the reference's UnevenMap object.  INTEGRATION.md 1 builds
+// the same block from UnevenMap's own members, which that very init has just loaded.  `mass`, `map_pcd`, `map_file` have no device side.
+template <class NodeHandle>
+inline uph_map_params loadMapParams(NodeHandle& nh, uph_map_params mp = uph_map_params{2, 10.0, 10.0, 0.2, 0.1, 0.1, 0.05, 0.1, 0.8, 0.05, 9.81}) {
+    int iter_num = mp.iter_num;
+    nh.getParam("uneven_map/iter_num", iter_num);
+    mp.iter_num = iter_num;
+    nh.getParam("uneven_map/map_size_x", mp.map_size_x);
+    nh.getParam("uneven_map/map_size_y", mp.map_size_y);
+    nh.getParam("uneven_map/ellipsoid_x", mp.ellipsoid_x);
+    nh.getParam("uneven_map/ellipsoid_y", mp.ellipsoid_y);
+    nh.getParam("uneven_map/ellipsoid_z", mp.ellipsoid_z);
+    nh.getParam("uneven_map/xy_resolution", mp.xy_resolution);
+    nh.getParam("uneven_map/yaw_resolution", mp.yaw_resolution);
+    nh.getParam("uneven_map/min_cnormal", mp.min_cnormal);
+    nh.getParam("uneven_map/max_rho", mp.max_rho);
+    nh.getParam("uneven_map/gravity", mp.gravity);
+    return mp;
+}
+// rosparam manager/... of PlanManager::init (plan_manager/src/plan_manager.cpp:9-13), for optimizeSE2TrajBatch's initial-guess stage
+template <class NodeHandle>
+inline uph_manager_params loadManagerParams(NodeHandle& nh, uph_manager_params mg = uph_manager_params{0.3, 0.5, 1.2, 2.0, 0.05, 0, 0.5}) {
+    nh.getParam("manager/piece_len", mg.piece_len);
+    nh.getParam("manager/mean_vel", mg.mean_vel);
+    nh.getParam("manager/init_time_times", mg.init_time_times);
+    nh.getParam("manager/yaw_piece_times", mg.yaw_piece_times);
+    nh.getParam("manager/init_sig_vel", mg.init_sig_vel);
+    return mg;
+}
+
 class UnevenMapHandle {            // owns a uph_map; what UnevenMap::Ptr is to the reference's optimiser
 public:
     // fp32_cells: store the cells as four floats (16 bytes) instead of four doubles -- km^2-scale grids (BASELINE.json configs[4])
@@ -236,21 +267,60 @@ public:
     double g_epsilon = 1.0e-3, min_step = 1.0e-32, inner_max_iter = 10000.0, delta = 1.0e-4;
     int mem_size = 256, past = 3, int_K = 16;
     bool in_opt = false;
+    bool in_test = false, in_debug = false;   // alm_traj_opt.h:56-57: loaded like the reference does; the test node's topics and the debug drawing stay on the host
 
     ALMTrajOpt() = default;
     ~ALMTrajOpt() { if (ctx_) uph_ctx_destroy(ctx_); }
     ALMTrajOpt(const ALMTrajOpt&) = delete;               // owns a device context (the reference's object is a value member that is never copied)
     ALMTrajOpt& operator=(const ALMTrajOpt&) = delete;
 
-    void setEnvironment(UnevenMapHandle* env) {          // alm_traj_opt.h:127-130
-        env_ = env;
-        if (ctx_) { uph_ctx_destroy(ctx_); ctx_ = nullptr; }
+    // void ALMTrajOpt::init(ros::NodeHandle& nh)  (back_end/src/alm_traj_opt.cpp:5-29): the 21 optimiser keys + in_test / in_debug, read with
+    // getParam exactly as the reference does -- a key the parameter server does not hold leaves the member as it was.  NodeHandle is a template
+    // parameter (ros::NodeHandle in the workspace; anything with getParam(const std::string&, T&) elsewhere).  The publishers / subscribers of
+    // :31-44 (RViz paths, the test node's goal topic) stay with the host.  Call order as in PlanManager::init (plan_manager.cpp:20-22):
+    // init, setFrontend, setEnvironment -- setEnvironment hands the members to the device context.
+    template <class NodeHandle>
+    void init(NodeHandle& nh) {
+        nh.getParam("alm_traj_opt/rho_T", rho_T);
+        nh.getParam("alm_traj_opt/rho_ter", rho_ter);
+        nh.getParam("alm_traj_opt/max_vel", max_vel);
+        nh.getParam("alm_traj_opt/max_acc_lon", max_acc_lon);
+        nh.getParam("alm_traj_opt/max_acc_lat", max_acc_lat);
+        nh.getParam("alm_traj_opt/max_kap", max_kap);
+        nh.getParam("alm_traj_opt/min_cxi", min_cxi);
+        nh.getParam("alm_traj_opt/max_sig", max_sig);
+        nh.getParam("alm_traj_opt/use_scaling", use_scaling);
+        nh.getParam("alm_traj_opt/rho", rho);
+        nh.getParam("alm_traj_opt/beta", beta);
+        nh.getParam("alm_traj_opt/gamma", gamma);
+        nh.getParam("alm_traj_opt/epsilon_con", epsilon_con);
+        nh.getParam("alm_traj_opt/max_iter", max_iter);
+        nh.getParam("alm_traj_opt/g_epsilon", g_epsilon);
+        nh.getParam("alm_traj_opt/min_step", min_step);
+        nh.getParam("alm_traj_opt/inner_max_iter", inner_max_iter);
+        nh.getParam("alm_traj_opt/delta", delta);
+        nh.getParam("alm_traj_opt/mem_size", mem_size);
+        nh.getParam("alm_traj_opt/past", past);
+        nh.getParam("alm_traj_opt/int_K", int_K);
+        nh.getParam("alm_traj_opt/in_test", in_test);
+        nh.getParam("alm_traj_opt/in_debug", in_debug);
+    }
+
+    // the members as the C-ABI's parameter block (what setEnvironment hands to uph_ctx_create)
+    uph_opt_params optParams() const {
         uph_opt_params p;
         p.rho_T = rho_T; p.rho_ter = rho_ter; p.max_vel = max_vel; p.max_acc_lon = max_acc_lon; p.max_acc_lat = max_acc_lat;
         p.max_kap = max_kap; p.min_cxi = min_cxi; p.max_sig = max_sig; p.use_scaling = use_scaling ? 1 : 0;
         p.rho = rho; p.beta = beta; p.gamma = gamma; p.epsilon_con = epsilon_con; p.max_iter = max_iter;
         p.g_epsilon = g_epsilon; p.min_step = min_step; p.inner_max_iter = inner_max_iter; p.delta = delta;
         p.mem_size = mem_size; p.past = past; p.int_K = int_K;
+        return p;
+    }
+
+    void setEnvironment(UnevenMapHandle* env) {          // alm_traj_opt.h:127-130
+        env_ = env;
+        if (ctx_) { uph_ctx_destroy(ctx_); ctx_ = nullptr; }
+        const uph_opt_params p = optParams();
         if (uph_ctx_create(env->get(), &p, &ctx_) != UPH_OK) throw std::runtime_error(std::string("uph_ctx_create: ") + uph_last_error());
     }
 
@@ -275,6 +345,7 @@ public:
         rs.x_final = x_.data(); rs.c_xy = cxy_.data(); rs.c_yaw = cyaw_.data();
         const int rc = uph_optimize_batch(ctx_, 1, &pr, &rs);
         in_opt = false;
+        last_multi_ = false;
         if (rc != UPH_OK) return 1;                       // solver error, as the reference reports a hard L-BFGS failure
         last_ = rs;
         rho = rs.rho_final;                               // rho is a member that persists (alm_traj_opt.h:137)
@@ -341,11 +412,27 @@ public:
         in_opt = true;
         std::vector<uph_ctx*> cs(1, ctx_);
         for (ALMTrajOpt* q : peers) cs.push_back(q->ctx_);
-        last_ctxs_.clear(); last_B_ = 0;
+        last_report_.clear(); last_multi_ = false;
         const int rc = uph_optimize_batch_multi(cs.data(), (int32_t)cs.size(), B, pr.data(), rs.data());
         in_opt = false;
-        if (rc == UPH_OK) { last_ctxs_ = cs; last_B_ = B; }                       // the contexts that now hold the shares of this batch (for the report)
         if (rc != UPH_OK) throw std::runtime_error(std::string("uph_optimize_batch_multi: ") + uph_last_error());
+        if (cs.size() > 1) {
+            // the batch now lives in shares on several devices.  The report rows are fetched HERE, while every context still holds its share
+            // of THIS batch (a peer may be destroyed or run another solve before the caller asks), and go back to the caller's order through
+            // uph_batch_origin
+            last_report_.assign((size_t)7 * B, 0.0);
+            for (uph_ctx* c : cs) {
+                const int n = uph_batch_count(c);
+                if (n <= 0) continue;                                                     // (a device whose share was empty or wholly unsupported)
+                std::vector<double> part((size_t)7 * n);
+                std::vector<int32_t> idx(n);
+                if (uph_report_batch(c, part.data()) != UPH_OK) throw std::runtime_error(std::string("uph_report_batch: ") + uph_last_error());
+                if (uph_batch_origin(c, idx.data()) != UPH_OK) throw std::runtime_error(std::string("uph_batch_origin: ") + uph_last_error());
+                for (int k = 0; k < n; k++)
+                    if (idx[k] >= 0 && idx[k] < B) for (int q = 0; q < 7; q++) last_report_[(size_t)7 * idx[k] + q] = part[(size_t)7 * k + q];
+            }
+            last_multi_ = true;
+        }
         for (int32_t b = 0; b < B; b++) {
             out.ret.push_back(rs[b].ret_code);
             out.jerk_cost.push_back(rs[b].jerk_cost);
@@ -365,31 +452,16 @@ public:
     }
     // the same report for every trajectory of the last call: [B][7] = max vx, ax, ay, cur, att, sigma, non-holonomic error (rows of
     // UPH_RET_UNSUPPORTED problems describe a placeholder, not a path)
-    // After a call with `peers` the batch lives in shares on several devices: every context reports its share and the rows go back to the CALLER's
-    // order through uph_batch_origin.
+    // After a call with `peers` the rows were collected from every device's share at the end of that call (cached here).
     std::vector<double> getMaxVxAxAyCurAttSigBatch() {
-        if (last_ctxs_.size() > 1) {
-            std::vector<double> o((size_t)7 * last_B_, 0.0);
-            for (uph_ctx* c : last_ctxs_) {
-                const int n = uph_batch_count(c);
-                if (n <= 0) continue;                                                     // (a device whose share was empty or wholly unsupported)
-                std::vector<double> part((size_t)7 * n);
-                std::vector<int32_t> idx(n);
-                if (uph_report_batch(c, part.data()) != UPH_OK) throw std::runtime_error(std::string("uph_report_batch: ") + uph_last_error());
-                if (uph_batch_origin(c, idx.data()) != UPH_OK) throw std::runtime_error(std::string("uph_batch_origin: ") + uph_last_error());
-                for (int k = 0; k < n; k++)
-                    if (idx[k] >= 0 && idx[k] < last_B_) for (int q = 0; q < 7; q++) o[(size_t)7 * idx[k] + q] = part[(size_t)7 * k + q];
-            }
-            return o;
-        }
+        if (last_multi_) return last_report_;
         const int B = uph_batch_count(ctx_);
         if (B <= 0) throw std::runtime_error("getMaxVxAxAyCurAttSig: no trajectory has been optimised on this object");
         std::vector<double> o((size_t)7 * B, 0.0);
         if (uph_report_batch(ctx_, o.data()) != UPH_OK) throw std::runtime_error(std::string("uph_report_batch: ") + uph_last_error());
         return o;
     }
-    // members PlanManager calls that have no device side: rosparam loading (set the public members instead), the A* handle, RViz output
-    template <class NodeHandle> void init(NodeHandle&) {}
+    // members PlanManager calls that have no device side: the A* handle, RViz output
     template <class FrontendPtr> void setFrontend(const FrontendPtr&) {}
     void visSE2Traj(const SE2Trajectory&) {}
     void visSE3Traj(const SE2Trajectory&) {}
@@ -415,8 +487,8 @@ private:
     uph_ctx* ctx_ = nullptr;
     uph_result last_{};
     std::vector<double> cxy_, cyaw_, x_;
-    std::vector<uph_ctx*> last_ctxs_;       // contexts holding the shares of the last optimizeSE2TrajBatch (this object's first)
-    int last_B_ = 0;
+    std::vector<double> last_report_;       // [B][7] of the last optimizeSE2TrajBatch over several devices, in the caller's order
+    bool last_multi_ = false;
 };
 
 
@@ -427,17 +499,41 @@ class KinoAstar {
 public:
     double yaw_resolution = 3.15, lambda_heu = 1.0, weight_r2 = 1.0, weight_so2 = 0.5, weight_v_change = 0.0, weight_delta_change = 0.0, weight_sigma = 10.0;
     double time_interval = 0.3, collision_interval = 0.06, oneshot_range = 1.0, wheel_base = 0.26, max_steer = 0.5, max_vel = 0.5;
+    bool in_test = false;
 
     KinoAstar() = default;
     ~KinoAstar() { if (k_) uph_kino_destroy(k_); }
     KinoAstar(const KinoAstar&) = delete;
     KinoAstar& operator=(const KinoAstar&) = delete;
 
-    template <class NodeHandle> void init(NodeHandle&) {}            // rosparam loading: set the public members instead (before setEnvironment)
+    // void KinoAstar::init(ros::NodeHandle& nh)  (front_end/src/kino_astar.cpp:5-20): nh.param with the REFERENCE's defaults -- a key the
+    // parameter server does not hold sets the member to that default (weight_so2 1.0, weight_sigma 0.0, time_interval 1.0, ...: not the YAML
+    // values the members start with).  The publishers / subscribers of :22-30 and the RViz model of :36-43 stay with the host; the Dubins
+    // radius wheel_base / tan(max_steer) (:34) is formed by uph_kino_create from the parameters setEnvironment hands over.
+    template <class NodeHandle>
+    void init(NodeHandle& nh) {
+        nh.param("kino_astar/yaw_resolution", yaw_resolution, 3.15);
+        nh.param("kino_astar/lambda_heu", lambda_heu, 1.0);
+        nh.param("kino_astar/weight_r2", weight_r2, 1.0);
+        nh.param("kino_astar/weight_so2", weight_so2, 1.0);
+        nh.param("kino_astar/weight_v_change", weight_v_change, 0.0);
+        nh.param("kino_astar/weight_delta_change", weight_delta_change, 0.0);
+        nh.param("kino_astar/weight_sigma", weight_sigma, 0.0);
+        nh.param("kino_astar/time_interval", time_interval, 1.0);
+        nh.param("kino_astar/collision_interval", collision_interval, 1.0);
+        nh.param("kino_astar/oneshot_range", oneshot_range, 1.0);
+        nh.param("kino_astar/wheel_base", wheel_base, 1.0);
+        nh.param("kino_astar/max_steer", max_steer, 1.0);
+        nh.param("kino_astar/max_vel", max_vel, 1.0);
+        nh.param("kino_astar/in_test", in_test, false);
+    }
+    uph_kino_params kinoParams() const {
+        return uph_kino_params{yaw_resolution, lambda_heu, weight_r2, weight_so2, weight_v_change, weight_delta_change, weight_sigma,
+                               time_interval, collision_interval, oneshot_range, wheel_base, max_steer, max_vel};
+    }
     void setEnvironment(UnevenMapHandle* env, int slots = 0) {        // kino_astar.h:170-178: binds the map, allocates the node pools
         if (k_) { uph_kino_destroy(k_); k_ = nullptr; }
-        const uph_kino_params kp{yaw_resolution, lambda_heu, weight_r2, weight_so2, weight_v_change, weight_delta_change, weight_sigma,
-                                 time_interval, collision_interval, oneshot_range, wheel_base, max_steer, max_vel};
+        const uph_kino_params kp = kinoParams();
         if (uph_kino_create(env->get(), &kp, slots, &k_) != UPH_OK) throw std::runtime_error(std::string("uph_kino_create: ") + uph_last_error());
     }
     // std::vector<Eigen::Vector3d> plan(const Eigen::Vector3d& start_state, const Eigen::Vector3d& end_state)   (kino_astar.cpp:67-236)
@@ -461,11 +557,27 @@ public:
         for (int32_t b = 0; b < B; b++) for (int k = 0; k < 3; k++) { s[(size_t)3 * b + k] = starts[b][k]; g[(size_t)3 * b + k] = goals[b][k]; }
         if (uph_kino_plan_batch(k_, B, s.data(), g.data(), path_cap, paths.data(), np.data(), status.data(), iter_num.data(), use.data(), 0, 0, nullptr) != UPH_OK)
             throw std::runtime_error(std::string("uph_kino_plan_batch: ") + uph_last_error());
+        std::vector<int32_t> longer;                    // queries whose front_end_path has more poses than path_cap: searched again with room for all of them
+        int32_t need = 0;                               // (the reference returns the whole path; a clipped one would end short of the goal)
         for (int32_t b = 0; b < B; b++) {
             if (status[b] != UPH_KINO_OK) continue;
-            const int n = np[b] < path_cap ? np[b] : path_cap;
-            out[b].resize((size_t)n);
-            for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) out[b][i][k] = paths[((size_t)b * path_cap + i) * 3 + k];
+            if (np[b] > path_cap) { longer.push_back(b); if (np[b] > need) need = np[b]; continue; }
+            out[b].resize((size_t)np[b]);
+            for (int i = 0; i < np[b]; i++) for (int k = 0; k < 3; k++) out[b][i][k] = paths[((size_t)b * path_cap + i) * 3 + k];
+        }
+        if (!longer.empty()) {
+            const int32_t L = (int32_t)longer.size();
+            std::vector<double> s2((size_t)3 * L), g2((size_t)3 * L), p2((size_t)3 * L * need);
+            std::vector<int32_t> np2(L), st2(L), it2(L), us2(L);
+            for (int32_t j = 0; j < L; j++) for (int k = 0; k < 3; k++) { s2[(size_t)3 * j + k] = s[(size_t)3 * longer[j] + k]; g2[(size_t)3 * j + k] = g[(size_t)3 * longer[j] + k]; }
+            if (uph_kino_plan_batch(k_, L, s2.data(), g2.data(), need, p2.data(), np2.data(), st2.data(), it2.data(), us2.data(), 0, 0, nullptr) != UPH_OK)
+                throw std::runtime_error(std::string("uph_kino_plan_batch: ") + uph_last_error());
+            for (int32_t j = 0; j < L; j++) {
+                const int32_t b = longer[j];
+                if (st2[j] != UPH_KINO_OK || np2[j] > need) { status[b] = UPH_KINO_INTERNAL; continue; }      // (the search is deterministic: not expected)
+                out[b].resize((size_t)np2[j]);
+                for (int i = 0; i < np2[j]; i++) for (int k = 0; k < 3; k++) out[b][i][k] = p2[((size_t)j * need + i) * 3 + k];
+            }
         }
         return out;
     }

@@ -84,6 +84,13 @@ class KinoAstar:
             if exp_cap > 0:
                 r["expanded"] = exp[b, :min(int(it[b]), exp_cap)].copy()
             out.append(r)
+        # a front_end_path longer than path_cap was clipped by the library (the node chain comes first, the Dubins shot that reaches the goal
+        # last): the reference returns the whole path, so those queries are searched again with room for all their poses
+        longer = [b for b in range(B) if st[b] == 0 and npth[b] > path_cap] if (path_cap > 1 and max_expand == 0) else []
+        if longer:
+            again = self.plan_batch(s[longer], g[longer], path_cap=int(npth[longer].max()), max_expand=0, exp_cap=0)
+            for b, r2 in zip(longer, again):
+                out[b]["path"], out[b]["n_path"] = r2["path"], r2["n_path"]
         self.last = out
         return out
 
