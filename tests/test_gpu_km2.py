@@ -168,10 +168,78 @@ def test_grid_beyond_4GiB_is_addressed_correctly(oracle):
         og, q, _ = window_oracle(big, p)
         a = oracle.OracleALM(og)
         fo, go_, _ = a.eval(a.setup(q))
-        assert abs(f[i] - fo) / abs(fo) < 1e-8 and rel(go_, gs[i]) < 1e-8, (i, f[i], fo)
+        assert abs(f[i] - fo) / abs(fo) < 1e-12 and rel(go_, gs[i]) < 1e-11, (i, f[i], fo)       # (1e-9 / 1e-8 before the trajectories had local frames)
     opt.set_rho(1.0)
     out = opt.optimize_batch(far)
     assert all(o["ret"] in (0, 2) for o in out) and np.mean([o["ret"] == 0 for o in out]) >= 0.5
+
+
+def test_far_from_origin_solves_meet_the_1e4_bar(oracle):
+    """positions hundreds of metres from the map origin.  Every trajectory is solved in a local frame a whole number of
+    cells away from the map's (uph_common.hpp TrajFrame), so the lookups' (x - origin) and (x - cell centre) differences are formed between
+    numbers of the path's own size -- like on the reference's 10 m maps, and like the oracle on the window of cells around the problem.  What
+    that must deliver, on a 640 m map (positions 200 .. 315 m from the origin): one evaluation at the hill scene's 1e-12 instead of the 1e-9
+    the map-frame arithmetic reached there, results returned in MAP coordinates, and north_star's 1e-4 on final way-points and cost
+    OUTRIGHT for every solve the oracle finishes within 120 L-BFGS iterations -- iteration-capped parameter sets (every ALM pass still runs)
+    and run_hill.yaml as shipped"""
+    import uneven_planner_amd as U
+    from conftest import rel
+    from oracle.oracle_py import window_oracle
+    from uneven_planner_amd import scenes
+    big = U.UnevenMap(dict(map_size_x=640.0, map_size_y=640.0, xy_resolution=0.25), storage="f32").fill_fbm()
+    nx, ny = int(big.voxel_num[0]), int(big.voxel_num[1])
+    far, seed = [], 7100
+    while len(far) < 48:
+        p = scenes.local_problems(1, seed0=seed, half=315.0, dmin=4.0, dmax=9.0, occ_r2=big.occ_r2_buffer, grid=(nx, ny, big.xy_resolution, big.map_origin[0], big.map_origin[1]))[0]
+        seed += 1
+        if max(abs(p["init_xy"][0, 0]), abs(p["init_xy"][1, 0])) > 200.0:
+            far.append(p)
+    wins = [window_oracle(big, p) for p in far]
+    opt = U.ALMTrajOpt(big)
+    opt.upload(far)
+    f, gs = opt.eval_batch(opt.x0_packed(far))
+    worst_f = worst_g = 0.0
+    for i, (og, q, _) in enumerate(wins):
+        a = oracle.OracleALM(og)
+        fo, go_, _ = a.eval(a.setup(q))
+        worst_f, worst_g = max(worst_f, abs(f[i] - fo) / abs(fo)), max(worst_g, rel(go_, gs[i]))
+    print("far-from-origin evaluation: f %.1e  grad %.1e" % (worst_f, worst_g))
+    assert worst_f < 1e-12 and worst_g < 1e-11
+    n_short = 0
+    for tag, prm in (("inner_max_iter=3", dict(inner_max_iter=3.0)), ("inner_max_iter=8", dict(inner_max_iter=8.0)), ("run_hill.yaml", None)):
+        o = U.ALMTrajOpt(big, prm)
+        o.set_rho(1.0)
+        dev = o.optimize_batch(far)
+        dx, short = [], 0
+        for d, p, (og, q, sh) in zip(dev, far, wins):
+            r = oracle.OracleALM(og, prm).optimize(q)
+            nin = p["inner_xy"].shape[1]
+            xo = np.array(r["x"], dtype=np.float64)
+            xo[1:1 + 2 * nin:2] += sh[0]
+            xo[2:2 + 2 * nin:2] += sh[1]
+            e = np.abs(d["x"] - xo).max() / np.abs(xo).max()
+            # (relative to the way-points' own size, 200 .. 315 m: the bar of the other scenes; the second figure is relative to the PATH's extent)
+            e_path = np.abs(d["x"][1:] - xo[1:]).max() / max(1.0, np.ptp(xo[1:1 + 2 * nin:2]), np.ptp(xo[2:2 + 2 * nin:2]))
+            dx.append(e_path)
+            if r["lbfgs_iters"] <= 120:
+                short += 1
+                assert d["ret"] == r["ret"] and e <= 1e-4 and e_path <= 1e-4 and abs(d["cost"] - r["cost"]) <= 1e-4 * abs(r["cost"]), (tag, r["lbfgs_iters"], e, e_path)
+            # the way-points came back in map coordinates, next to the problem's own end points
+            assert np.abs(d["x"][1:1 + 2 * nin:2] - p["init_xy"][0, 0]).max() < 40.0 and np.abs(d["x"][2:2 + 2 * nin:2] - p["init_xy"][1, 0]).max() < 40.0
+        print("%s: %d of %d oracle solves within 120 iterations, all within 1e-4; way-point error relative to the path extent: median %.1e max %.1e" % (tag, short, len(far), np.median(dx), np.max(dx)))
+        if prm is not None and prm["inner_max_iter"] == 3.0:
+            assert short == len(far)
+        n_short += short
+    assert n_short >= len(far) + 8
+    # the trajectory the caller pulls (coefficients, SE2Traj message) is in map coordinates as well: piece start points = way-points
+    o = U.ALMTrajOpt(big, dict(inner_max_iter=3.0))
+    o.set_rho(1.0)
+    out = o.optimize_batch(far[:4])
+    for b in range(4):
+        msg = o.getTraj(b).to_msg()
+        nin = far[b]["inner_xy"].shape[1]
+        assert np.abs(msg["pos_pts"][0, :2] - far[b]["init_xy"][:, 0]).max() < 1e-9 and np.abs(msg["pos_pts"][-1, :2] - far[b]["end_xy"][:, 0]).max() < 1e-9
+        assert np.abs(msg["pos_pts"][1:-1, :2] - out[b]["x"][1:1 + 2 * nin].reshape(nin, 2)).max() < 1e-9
 
 
 def test_fp32_sample_mode_tracks_the_fp64_path(small_maps):
@@ -263,5 +331,5 @@ def test_full_size_km2_workload_properties():
         alm = O.OracleALM(g_)
         x0 = alm.setup(q_)
         fo, go, _ = alm.eval(x0)
-        assert abs(f[k] - fo) <= 1e-9 * abs(fo), i
+        assert abs(f[k] - fo) <= 1e-12 * abs(fo), i
     print("km2 full size: kernel %.1f ms, %.0f traj-opts/s, converged %.3f" % (st["kernel_ms"], B / (st["kernel_ms"] + st["prepare_ms"]) * 1e3, (rets == 0).mean()))

@@ -164,7 +164,10 @@ def load():
         except ImportError:
             pass
         L = C.CDLL(LIB_PATH)
+        variant = bool(os.environ.get("UNEVENHIP_LIB"))
         for name, (res, args) in SYMBOLS.items():
+            if variant and not hasattr(L, name):
+                continue                # an A/B build of an earlier source state (tools/build_variants.sh) may predate a symbol; calling it raises
             fn = getattr(L, name)       # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

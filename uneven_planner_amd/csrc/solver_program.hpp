@@ -37,6 +37,12 @@ namespace uph {
 #ifndef UPH_GRID_FROM_MEM
 #define UPH_GRID_FROM_MEM 1
 #endif
+// diagnostic builds only (tools/pmc_phases.sh): phases of an objective evaluation that run -- 1 generate + expand, 2 samples, 4 scatter, 8 adjoint.
+// A masked build computes nonsense (stale coefficients / records / gradients); it exists so that hardware counters of the penalty kernel can be
+// attributed to a phase as (all phases) - (all but one).  The shipped library has every phase: the conditions fold away.
+#ifndef UPH_PHASE_MASK
+#define UPH_PHASE_MASK 15
+#endif
 #ifndef UPH_SC_XB
 #define UPH_SC_XB 9
 #endif
@@ -269,6 +275,18 @@ struct Solver {
     }
 
     // ------------------------------------------------------------------ per-sample kinematics + terrain
+    // the grid descriptor as this trajectory's lookups see it: the map's, or -- far from the map's origin -- its local frame (TrajFrame)
+    static UPH_HD void applyFrame(GridDev& g, const TrajFrame& f) {
+        g.origin[0] = f.fo[0]; g.origin[1] = f.fo[1];
+        g.lo[0] = f.lo[0]; g.lo[1] = f.lo[1]; g.hi[0] = f.hi[0]; g.hi[1] = f.hi[1];
+        g.ix_off = f.ioff[0]; g.iy_off = f.ioff[1];
+    }
+    UPH_HD GridDev framedGrid() const {
+        GridDev g = grid;
+        if (bd.frames != nullptr) applyFrame(g, bd.frames[bidx]);
+        return g;
+    }
+
     template <class R>
     struct KinT {
         R b0[6], b1[6], b2[6], b3[6];
@@ -299,9 +317,21 @@ struct Solver {
         for (int k = 0; k < NWORD; k++) w[k] = T[k];
         GridDev gl;
         __builtin_memcpy(&gl, w, sizeof(GridDev));
+        if (bd.frames != nullptr) {                 // (wave-uniform: a kernel argument) the trajectory's local frame, through the same kind of scalar loads
+            gw_t F = (gw_t)(const void*)(bd.frames + bidx);
+            asm volatile("" : "+s"(F));
+            constexpr int FWORD = (int)(sizeof(TrajFrame) / 8);
+            unsigned long long fw[FWORD];
+#pragma unroll
+            for (int k = 0; k < FWORD; k++) fw[k] = F[k];
+            TrajFrame fr;
+            __builtin_memcpy(&fr, fw, sizeof(TrajFrame));
+            applyFrame(gl, fr);
+        }
         terrainBase<R>(gl, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
 #else
-        terrainBase<R>(grid, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
+        const GridDev gl = framedGrid();
+        terrainBase<R>(gl, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
 #endif
         const R zx = S_.zx, zy = S_.zy;
         const R cc = sqrt(1.0 - zx * zx - zy * zy);                 // uneven_map.h:327-348
@@ -358,7 +388,7 @@ struct Solver {
         S_.lon_acc = S_.acc[0] * S_.cyaw + S_.acc[1] * S_.syaw;
         S_.lat_acc = S_.acc[0] * (-S_.syaw) + S_.acc[1] * S_.cyaw;
         S_.yawn = yawn; S_.cw = cw; S_.sw = sw;
-        if constexpr (WITH_GRADS) terrainAllWithGrad(grid, S_.pos[0], S_.pos[1], yawn, cw, sw, S_.tv, S_.tg);   // :778  (initScaling: R = double)
+        if constexpr (WITH_GRADS) terrainAllWithGrad(framedGrid(), S_.pos[0], S_.pos[1], yawn, cw, sw, S_.tv, S_.tg);   // :778  (initScaling: R = double)
         else terrainValuesOnly<R>(S_);
         S_.vx = S_.v_norm * S_.tv[0];                                   // :813-817
         S_.wz = dyaw * S_.tv[5];
@@ -808,13 +838,13 @@ struct Solver {
         evals++;
         long long t0 = wg.clock();
         if (t_last_eval_end) cyc[5] += t0 - t_last_eval_end;      // from the end of the previous evaluation (or of the two-loop) to here
-        generate<STEP>(xin, st);
+        if (UPH_PHASE_MASK & 1) generate<STEP>(xin, st);
         // (values that stay alive across the evaluation's barriers are parked in scalar registers: a "uniform" double left in a
         // VGPR competes with the sample code for registers and ends up in scratch)
         const double tau = wg.bcast(xin[0]);
         const double jw = wg.bcast(P.use_scaling ? scale_trick_jerk * scale_fx : scale_fx);      // :308-310, 322-332
-        double js[3];
-        expand(xin, jw, js);
+        double js[3] = {0.0, 0.0, 0.0};
+        if (UPH_PHASE_MASK & 1) expand(xin, jw, js);
         long long t1 = wg.clock(); cyc[0] += t1 - t0;
         last_jerk = js[0];
         const double jerk_cost = wg.bcast(P.use_scaling ? js[0] * scale_fx * scale_trick_jerk : js[0] * scale_fx);
@@ -822,17 +852,17 @@ struct Solver {
         double sm[3] = {0.0, 0.0, 0.0};
         for (int s0 = 0; s0 < S; s0 += CH) {
             const int cnt = S - s0 < CH ? S - s0 : CH;
-            double part[3];
+            double part[3] = {0.0, 0.0, 0.0};
             t0 = wg.clock();
-            wg.template sum<3>(cnt, part, [&](int t, double* acc) { sampleEval<false, SR>(s0 + t, t, acc); });
+            if (UPH_PHASE_MASK & 2) wg.template sum<3>(cnt, part, [&](int t, double* acc) { sampleEval<false, SR>(s0 + t, t, acc); });
             t1 = wg.clock(); cyc[1] += t1 - t0;
             sm[0] += part[0]; sm[1] += part[1]; sm[2] += part[2];
-            scatterChunk(s0, cnt);
+            if (UPH_PHASE_MASK & 4) scatterChunk(s0, cnt);
             cyc[2] += wg.clock() - t1;
         }
         t1 = wg.clock();
-        double chx, chy, gdw;
-        adjoint(chx, chy, gout, &gdw);
+        double chx = 0.0, chy = 0.0, gdw = 0.0;
+        if (UPH_PHASE_MASK & 8) adjoint(chx, chy, gout, &gdw);
         t0 = wg.clock(); cyc[3] += t0 - t1;
         const double gTx = js[1] * jw + sm[1] + chx;       // sum_i gdTxy(i) after calGradCTtoQT
         const double gTy = js[2] * jw + sm[2] + chy;
@@ -1388,6 +1418,7 @@ struct Solver {
             cnt = (int)cnt_d[0];
         }
         const double gravity = grid.gravity;
+        const GridDev fgrid = framedGrid();
         // sample q sits at the reference's running sum t += 0.01 (q additions): every lane walks its own samples in increasing order
         // and keeps adding where it stopped
         double tcur = 0.0;
@@ -1424,7 +1455,7 @@ struct Solver {
             sincosFast(yaw, sy_, cy_);
             const double cw = cy_, sw = sy_;
             double tv[7];
-            terrainVariables(grid, p[0], p[1], yawn, cw, sw, tv, nullptr);
+            terrainVariables(fgrid, p[0], p[1], yawn, cw, sw, tv, nullptr);
             const double vnorm = sqrt(v[0] * v[0] + v[1] * v[1]);
             const double lon = a[0] * cy_ + a[1] * sy_;
             const double lat = -a[0] * sy_ + a[1] * cy_;

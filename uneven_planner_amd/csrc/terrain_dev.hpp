@@ -51,8 +51,10 @@ UPH_HD void locate(const GridDev& g, R x, R y, R yaw, CornersT<R>& c) {
     d = d - TWO_PI * rint(d * INV_TWO_PI);
     c.dyaw = d * g.yaw_inv;
     // boundIndex :398-409: clamp x,y; wrap yaw modulo nyaw
-    const int x0 = clampIdx(ix, g.nx - 1), x1 = clampIdx(ix + 1, g.nx - 1);
-    const int y0 = clampIdx(iy, g.ny - 1), y1 = clampIdx(iy + 1, g.ny - 1);
+    // (a trajectory's local frame counts cells from its own corner: ix_off / iy_off lead back to the grid's index; zero in the map's frame)
+    const int gx = ix + g.ix_off, gy = iy + g.iy_off;
+    const int x0 = clampIdx(gx, g.nx - 1), x1 = clampIdx(gx + 1, g.nx - 1);
+    const int y0 = clampIdx(gy, g.ny - 1), y1 = clampIdx(gy + 1, g.ny - 1);
     // yaw passed isInMap and wm lies in [-pi, pi], so iw lies in [-1, nyaw]: ONE conditional wrap each way is boundIndex's modulo for
     // iw and iw + 1 alike
     int w0 = iw, w1 = iw + 1;

@@ -675,6 +675,8 @@ struct uph_ctx {
     std::vector<int> rejected;              // per problem: 0, or the status code that made it unsupported (solved as a placeholder, reported as UPH_RET_UNSUPPORTED)
     int n_rejected = 0;
     bool all_rejected = false;              // the last upload failed because EVERY problem was unsupported (not because of a misuse or a resource limit)
+    std::vector<TrajFrame> frames;          // per-trajectory local frames of the uploaded batch (empty: the map's own frame, uph_common.hpp TrajFrame)
+    DevBuf d_frames;
     std::vector<int> origin;                // batch loaded by uph_optimize_batch_multi: the caller's index of each problem of this context's share (empty: identity)
     bool sample_f32 = false;                // fp32 sample arithmetic (uph_ctx_set_sample_precision)
     int xcd_group = 0;                      // experiment knob (uph_ctx_set_xcd_locality): > 0 = permute the launch order inside groups of that many workgroups for per-XCD L2 locality
@@ -724,6 +726,7 @@ static BatchDev makeBatchDev(uph_ctx* c) {
     bd.trace_cap = c->trace_cap_up;
     bd.order = c->d_order.as<int>();
     bd.thomas = c->d_thomas.as<double>();
+    bd.frames = c->frames.empty() ? nullptr : c->d_frames.as<TrajFrame>();
     bd.grid_mem = c->d_gridmem.as<GridDev>();
     bd.params_mem = c->d_parammem.as<OptParams>();
     bd.rs_d = c->d_rsd.as<double>(); bd.rs = c->d_rs.as<double>();
@@ -844,6 +847,18 @@ static int launchSolver(uph_ctx* c, int mode, int repeat, bool async = false, hi
     return UPH_OK;
 }
 
+// x of every trajectory, packed, in MAP coordinates -> the resident x (way-points translated into each trajectory's local frame, if any)
+static int uploadPackedX(uph_ctx* c, const double* x_packed) {
+    if (c->frames.empty()) { HIPCHK(hipMemcpy(c->d_x.p, x_packed, 8 * c->sum_n, hipMemcpyHostToDevice)); return UPH_OK; }
+    std::vector<double> xl(x_packed, x_packed + c->sum_n);
+    for (int b = 0; b < c->B; b++) {
+        const TrajDesc& t = c->desc[b];
+        for (int i = 0; i < 2 * (t.Nxy - 1); i++) xl[t.off_x + 1 + i] -= c->frames[b].shift[i & 1];
+    }
+    HIPCHK(hipMemcpy(c->d_x.p, xl.data(), 8 * c->sum_n, hipMemcpyHostToDevice));
+    return UPH_OK;
+}
+
 extern "C" {
 
 const char* uph_last_error(void) { return g_last_error.c_str(); }
@@ -899,7 +914,7 @@ void uph_ctx_destroy(uph_ctx* c) {
     hipSetDevice(c->device);             // not via c->map: the map may already have been destroyed by the caller
     for (void* p : c->op_allocs) hipFree(p);
     DevBuf* bufs[] = {&c->d_ops, &c->d_desc, &c->d_state, &c->d_x, &c->d_gout, &c->d_dual, &c->d_res, &c->d_scl, &c->d_cxy, &c->d_cyaw,
-                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas, &c->d_rsd, &c->d_rs, &c->d_gridmem, &c->d_parammem};
+                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas, &c->d_rsd, &c->d_rs, &c->d_gridmem, &c->d_parammem, &c->d_frames};
     for (DevBuf* b : bufs) b->release();
     HostBuf* hbufs[] = {&c->h_x, &c->h_cxy, &c->h_cyaw, &c->h_dual, &c->h_res, &c->h_scl};
     for (HostBuf* b : hbufs) b->release();
@@ -1001,6 +1016,32 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         if (rj) { if (!c->n_rejected) { why = msg; first_rj = rj; } c->n_rejected++; }
     }
     if (c->n_rejected == B) { c->rejected.clear(); c->n_rejected = 0; c->all_rejected = true; setError(why); return first_rj; }
+    // Local frames (uph_common.hpp TrajFrame): on a grid that reaches further than FRAME_EXTENT from its origin every trajectory is solved in
+    // coordinates relative to the cell corner nearest the middle of its initial path's bounding box -- a whole number of cells away from the
+    // grid's origin, so the translation of the inputs is exact and the lookups see the same cells.  The reference's maps (10 m x 10 m) stay
+    // in the map's frame: frames empty, the plain lookup code path.
+    c->frames.clear();
+    if (std::max(std::max(std::fabs(tg.minb[0]), std::fabs(tg.maxb[0])), std::max(std::fabs(tg.minb[1]), std::fabs(tg.maxb[1]))) > FRAME_EXTENT) {
+        c->frames.resize(B);
+        for (int b = 0; b < B; b++) {
+            const uph_problem& q = *pp[b];
+            double lo[2] = {std::min(q.init_xy[0], q.end_xy[0]), std::min(q.init_xy[1], q.end_xy[1])};
+            double hi[2] = {std::max(q.init_xy[0], q.end_xy[0]), std::max(q.init_xy[1], q.end_xy[1])};
+            for (int i = 0; i < q.n_inner_xy; i++)
+                for (int d = 0; d < 2; d++) { lo[d] = std::min(lo[d], q.inner_xy[2 * i + d]); hi[d] = std::max(hi[d], q.inner_xy[2 * i + d]); }
+            TrajFrame& f = c->frames[b];
+            const int nn[2] = {tg.nx, tg.ny};
+            for (int d = 0; d < 2; d++) {
+                long long ci = std::llround((0.5 * (lo[d] + hi[d]) - tg.origin[d]) * tg.xy_inv);
+                ci = ci < 0 ? 0 : (ci > nn[d] ? nn[d] : ci);                     // (a path outside the map: the frame stays at the map's edge)
+                f.ioff[d] = (int)ci;
+                f.shift[d] = tg.origin[d] + (double)ci * tg.xy_res;
+                f.fo[d] = 0.0;
+                f.lo[d] = tg.lo[d] - f.shift[d];
+                f.hi[d] = tg.hi[d] - f.shift[d];
+            }
+        }
+    }
     for (int b = 0; b < B; b++) {
         const uph_problem& pr = *pp[b];
         const int Nxy = pr.n_inner_xy + 1, Nyaw = pr.n_inner_yaw + 1;
@@ -1013,6 +1054,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         t.off_x = on; t.off_s = os; t.off_cxy = ocx; t.off_cyaw = ocy; t.off_hist = oh;
         for (int k = 0; k < 6; k++) { t.init_xy[k] = pr.init_xy[k]; t.end_xy[k] = pr.end_xy[k]; }
         for (int k = 0; k < 3; k++) { t.init_yaw[k] = pr.init_yaw[k]; t.end_yaw[k] = pr.end_yaw[k]; }
+        if (!c->frames.empty()) for (int d = 0; d < 2; d++) { t.init_xy[d] -= c->frames[b].shift[d]; t.end_xy[d] -= c->frames[b].shift[d]; }      // the positions P of {P, V, A}
         on += t.n; os += t.S; ocx += 12 * Nxy; ocy += 6 * Nyaw; oh += (int64_t)mem * histRowDoubles(t.n);
         c->fp_bytes[b] = (Solver<DevWG<64>>::ldsDoubles(Nxy, Nyaw, t.n, c->lanes, mem, c->P.int_K) + 2 * (c->lanes / 64) * DevWG<64>::MAXM) * sizeof(double);
         lds_d = std::max(lds_d, Solver<DevWG<64>>::ldsDoubles(Nxy, Nyaw, t.n, c->lanes, mem, c->P.int_K));
@@ -1028,7 +1070,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     if (c->d_desc.ensure(sizeof(TrajDesc) * B) || c->d_state.ensure(sizeof(TrajState) * B) || c->d_x.ensure(8 * on) || c->d_x0.ensure(8 * on) || c->d_gout.ensure(8 * on) ||
         c->d_dual.ensure(8 * 7 * os) || c->d_res.ensure(8 * 7 * os) || c->d_scl.ensure(8 * 7 * os) || c->d_cxy.ensure(8 * ocx) || c->d_cyaw.ensure(8 * ocy) ||
         c->d_hist.ensure(8 * oh) || c->d_report.ensure(8 * 7 * B) || c->d_order.ensure(4 * B) ||
-        c->d_trace.ensure(8 * (size_t)std::max(1, c->trace_cap) * B))
+        c->d_trace.ensure(8 * (size_t)std::max(1, c->trace_cap) * B) || c->d_frames.ensure(sizeof(TrajFrame) * std::max<size_t>(1, c->frames.size())))
         return UPH_ERR_HIP;
     // x0 = [tau | Pxy | Pyaw]  (alm_traj_opt.cpp:206-216)
     std::vector<double> x0(on);
@@ -1036,7 +1078,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
         const uph_problem& pr = *pp[b];
         double* x = x0.data() + c->desc[b].off_x;
         x[0] = logC2(pr.total_time);
-        for (int i = 0; i < 2 * pr.n_inner_xy; i++) x[1 + i] = pr.inner_xy[i];
+        for (int i = 0; i < 2 * pr.n_inner_xy; i++) x[1 + i] = pr.inner_xy[i] - (c->frames.empty() ? 0.0 : c->frames[b].shift[i & 1]);
         for (int i = 0; i < pr.n_inner_yaw; i++) x[1 + 2 * pr.n_inner_xy + i] = pr.inner_yaw[i];
     }
     // Launch order: most expensive solves first (longest-processing-time list scheduling), so that the tail of a launch -- workgroups
@@ -1098,6 +1140,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     HIPCHK(hipMemcpy(c->d_x.p, x0.data(), 8 * on, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_x0.p, x0.data(), 8 * on, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_order.p, c->order.data(), 4 * B, hipMemcpyHostToDevice));
+    if (!c->frames.empty()) HIPCHK(hipMemcpy(c->d_frames.p, c->frames.data(), sizeof(TrajFrame) * B, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_state.p, c->state_host.data(), sizeof(TrajState) * B, hipMemcpyHostToDevice));
     // duals = 0, residuals = 0, scales = 1 (alm_traj_opt.cpp:193-203) so that the test hooks see a defined state
     // (all on the context's own stream, waited for with a STREAM synchronise: a device-wide one would block this host thread on every other
@@ -1237,11 +1280,17 @@ int uph_batch_download(uph_ctx* c, uph_result* results) {
         o.cost = s.f; o.jerk_cost = s.jerk_cost; o.piece_T_xy = s.T_xy; o.piece_T_yaw = s.T_yaw; o.rho_final = s.rho; o.scale_fx = s.scale_fx;
         if (tiled) {                     // lookups outside the held rows were clamped to the tile: such a result is not the whole grid's
             const double* xf = x + t.off_x;
+            const double sx = c->frames.empty() ? 0.0 : c->frames[b].shift[0];
             for (int i = 0; i < t.Nxy - 1; i++)
-                if ((tg.x_off > 0 && xf[1 + 2 * i] < tile_lo + 2.0 * tg.xy_res) || (tg.x_off + tg.nx_hold < tg.nx && xf[1 + 2 * i] > tile_hi - 2.0 * tg.xy_res)) o.ret_code = UPH_RET_LEFT_TILE;
+                if ((tg.x_off > 0 && xf[1 + 2 * i] + sx < tile_lo + 2.0 * tg.xy_res) || (tg.x_off + tg.nx_hold < tg.nx && xf[1 + 2 * i] + sx > tile_hi - 2.0 * tg.xy_res)) o.ret_code = UPH_RET_LEFT_TILE;
         }
         if (o.x_final) std::memcpy(o.x_final, x + t.off_x, 8 * t.n);
         if (o.c_xy) std::memcpy(o.c_xy, cxy + t.off_cxy, 8 * 12 * t.Nxy);
+        if (!c->frames.empty()) {        // back into map coordinates: the way-points and every piece's constant coefficient (row 6 i of c_xy)
+            const TrajFrame& f = c->frames[b];
+            if (o.x_final) for (int i = 0; i < 2 * (t.Nxy - 1); i++) o.x_final[1 + i] += f.shift[i & 1];
+            if (o.c_xy) for (int i = 0; i < t.Nxy; i++) for (int d = 0; d < 2; d++) o.c_xy[12 * i + d] += f.shift[d];
+        }
         if (o.c_yaw) std::memcpy(o.c_yaw, cyaw + t.off_cyaw, 8 * 6 * t.Nyaw);
         if (!o.lambda && !o.mu && !o.hx && !o.gx && !o.scale_cx) continue;
         const int S = t.S;
@@ -1372,7 +1421,7 @@ int uph_eval_batch(uph_ctx* c, const double* x_packed, double* f, double* grad_p
     if (c && c->n_rejected) { setError("packed-array hooks need a batch without unsupported problems (uph_result.ret_code == UPH_RET_UNSUPPORTED)"); return UPH_ERR_INVALID; }
     if (!c || c->B <= 0 || repeat < 1) { setError("uph_eval_batch: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
-    if (x_packed) HIPCHK(hipMemcpy(c->d_x.p, x_packed, 8 * c->sum_n, hipMemcpyHostToDevice));
+    if (x_packed) { const int rx = uploadPackedX(c, x_packed); if (rx != UPH_OK) return rx; }
     int r = launchSolver(c, 0, repeat);
     if (r != UPH_OK) return r;
     r = refreshStates(c);
@@ -1425,8 +1474,7 @@ int uph_batch_set_x(uph_ctx* c, const double* x_packed) {
     if (c && c->n_rejected) { setError("packed-array hooks need a batch without unsupported problems (uph_result.ret_code == UPH_RET_UNSUPPORTED)"); return UPH_ERR_INVALID; }
     if (!c || c->B <= 0 || !x_packed) { setError("uph_batch_set_x: bad arguments"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpy(c->d_x.p, x_packed, 8 * c->sum_n, hipMemcpyHostToDevice));
-    return UPH_OK;
+    return uploadPackedX(c, x_packed);
 }
 // the ALM loop of optimizeSE2Traj (alm_traj_opt.cpp:234-271) from the RESIDENT x, duals, scales and rho -- no reset, no initScaling --
 // for at most max_passes passes (0 = until it ends); a solve stopped by the cap reports ret_code 3

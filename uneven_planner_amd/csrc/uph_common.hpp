@@ -67,6 +67,7 @@ enum {
 struct GridDev {
     int nx, ny, nyaw;             // dimensions of the WHOLE grid (index clamping, uneven_map.h:398-409)
     int x_off, nx_hold;           // rows held in memory: global x index of the first one and their number (x_off = 0, nx_hold = nx unless the map is a tile)
+    int ix_off = 0, iy_off = 0;   // local frame of one trajectory (TrajFrame): the lookup's floor() index counts cells from the frame's corner, + these = the grid's index
     double xy_res, yaw_res, xy_inv, yaw_inv;
     double origin[3], minb[3], maxb[3];
     double lo[3], hi[3];          // minb + 1e-4, maxb - 1e-4 (isInMap), formed once on the host so that they stay scalar operands
@@ -105,6 +106,21 @@ struct MincoOp {
     int N;
     const double* Wt;   // knot operator, [col][row]: 2(N-1) rows (v_j, a_j of the interior knots) x (N+5) columns of beta
     const double* Wr;   // the same, [row][col]
+};
+
+// Local frame of one trajectory on a grid whose coordinates are large (BASELINE.json configs[4]: +-500 m).  The reference's lookup forms
+// (x - origin) and x - cell centre (uneven_map.h:275-283) in map coordinates; 400 m from the origin those differences carry 1e-13 of relative
+// rounding where the 10 m maps of the reference carry 1e-15 -- the seed the optimiser then amplifies.  On such a grid every
+// trajectory is solved in a frame translated by a WHOLE number of cells to a cell corner next to its own path (shift = origin + ioff * resolution:
+// the translation of every way-point and end state is exact, the cells are the same cells): the lookups run with the frame's origin (0) and bounds
+// and add ioff to the cell index.  Way-points and the t^0 coefficients return in map coordinates.  Grids within +-FRAME_EXTENT of the origin --
+// every map of the reference -- keep the map's own frame (BatchDev::frames == nullptr: the arithmetic and the code path of the plain lookup).
+constexpr double FRAME_EXTENT = 32.0;
+struct TrajFrame {
+    double fo[2];               // frame origin that replaces GridDev::origin[0..1] in the lookup (0: the frame's corner IS a cell corner)
+    double lo[2], hi[2];        // GridDev::lo / hi [0..1] in frame coordinates (isInMap)
+    double shift[2];            // map coordinate of the frame's corner: frame = map - shift
+    int ioff[2];                // cell index of the frame's corner
 };
 
 // One trajectory of a batch: sizes and offsets into the packed batch arrays
@@ -149,6 +165,7 @@ struct BatchDev {
     const int* order;   // optional launch order: workgroup w solves trajectory order[w] (longest first)
     const OptParams* params_mem;   // the optimiser parameters in device memory, for the same reason as grid_mem
     const GridDev* grid_mem;   // the grid descriptor in device memory (same content as the kernel argument): the penalty kernel re-reads it with scalar loads per sample chunk instead of holding ~50 SGPRs across the whole solve
+    const TrajFrame* frames;   // per-trajectory local frames (nullptr: every trajectory of the batch lives in the map's own frame)
     const double* thomas;   // block-LU factors of the MINCO knot system, THOMAS_DOUBLES (minco_op_host.hpp); shared by every trajectory, copied to LDS per workgroup
 };
 
