@@ -157,17 +157,41 @@ def single_process(args):
     sync()
     dt = time.perf_counter() - t0
     rets = np.array([r["ret"] for r in opts[0].download(full=False)])
-    res = {"metric": "MINCO traj-opts/sec (batch)", "value": B * N * args.steps / dt, "unit": "traj-opts/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "hill scene (synthetic hill cloud, map built on the devices by uph_map_build_multi), batch of %d random start/goal full ALM solves per GPU, run_hill.yaml params" % B,
-                      "batch_per_gpu": B, "grid": [nx, ny, int(m0.voxel_num[2])], "launcher": "single process, C-ABI multi-GPU entries (no torch.distributed)",
-                      "rccl_world": N if stages2.get("via_rccl") else 1, "parallelism": "dp%d" % N},
-           "per_rank_ms_per_step": [dt / args.steps * 1e3] * N,
-           "per_gpu_kernel_ms": [float(v) for v in np.mean(np.array(kms), axis=0)], "converged_frac": float((rets == 0).mean()),
-           "map_build_multi": dict(first_call_s=map_build_s, warm_call_s=map_build_warm_s, first=stages, warm=stages2,
-                                   per_device_slab_stages_ms=[mm.build_stats()["stages_ms"] for mm in maps],
-                                   note="first call includes the RCCL clique creation (~1 s) and the scratch allocations; the timed region never contains a map build")}
+    res = single_process_line(args, N, B, dt, np.mean(np.array(kms), axis=0), float((rets == 0).mean()), [nx, ny, int(m0.voxel_num[2])], stages, stages2, map_build_s, map_build_warm_s,
+                              [mm.build_stats()["stages_ms"] for mm in maps])
     print(json.dumps(res), flush=True)
+
+
+def single_process_line(args, N, B, dt, per_gpu_kernel_ms, converged_frac, grid, stages, stages2, map_build_s, map_build_warm_s, per_device_stages):
+    """the JSON line of --single-process (one place, so that the CPU tier's dry run of an 8-GPU node prints the line's real shape)"""
+    return {"metric": "MINCO traj-opts/sec (batch)", "value": B * N * args.steps / dt, "unit": "traj-opts/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "hill scene (synthetic hill cloud, map built on the devices by uph_map_build_multi), batch of %d random start/goal full ALM solves per GPU, run_hill.yaml params" % B,
+                       "batch_per_gpu": B, "grid": grid, "launcher": "single process, C-ABI multi-GPU entries (no torch.distributed)",
+                       "rccl_world": N if stages2.get("via_rccl") else 1, "parallelism": "dp%d" % N},
+            "per_rank_ms_per_step": [dt / args.steps * 1e3] * N,
+            "per_gpu_kernel_ms": [float(v) for v in per_gpu_kernel_ms], "converged_frac": converged_frac,
+            "map_build_multi": dict(first_call_s=map_build_s, warm_call_s=map_build_warm_s, first=stages, warm=stages2,
+                                    per_device_slab_stages_ms=per_device_stages,
+                                    note="first call includes the RCCL clique creation (~1 s) and the scratch allocations; the timed region never contains a map build")}
+
+
+def single_process_dry_run(args):
+    """UPH_BENCH_SPAWN_ECHO=1 with --single-process (CPU tier, tests/test_dist_cpu.py): every host-side decision the N-GPU run takes -- the x-slab
+    each device fits and whether the all-gather runs in place (uph_multi_slab_plan), the seeds of each device's problems -- and the line's shape,
+    without touching a device"""
+    import ctypes as C
+    import uneven_planner_amd as U
+    L = U._lib.load()
+    N, B = args.gpus, args.batch or 16384
+    nx = int(math.ceil(10.0 / 0.05))                                         # run_hill.yaml: map_size_x / xy_resolution (uneven_map.cpp:108)
+    x0, x1, per, inpl = (C.c_int32 * N)(), (C.c_int32 * N)(), C.c_int32(0), C.c_int32(0)
+    U._lib.check(L.uph_multi_slab_plan(nx, N, x0, x1, C.byref(per), C.byref(inpl)), "uph_multi_slab_plan")
+    fake = {"fit_ms": 0.0, "exchange_ms": 0.0, "commit_ms": 0.0, "exchange_device_ms": 0.0, "via_rccl": N > 1}
+    line = single_process_line(args, N, B, 1.0, [0.0] * N, 0.0, [nx, nx, 64], fake, fake, 0.0, 0.0, [None] * N)
+    line["dry_run"] = {"slabs": [[int(x0[g]), int(x1[g])] for g in range(N)], "rows_per_slab": int(per.value), "all_gather_in_place": bool(inpl.value),
+                       "seed0_per_device": [1000 + g * B for g in range(N)]}
+    print(json.dumps(line), flush=True)
 
 
 def main():
@@ -202,6 +226,8 @@ def main():
         spawn_ranks(args.gpus, sys.argv[1:])
         return
     if args.single_process:
+        if os.environ.get("UPH_BENCH_SPAWN_ECHO") == "1":
+            return single_process_dry_run(args)
         return single_process(args)
     km2 = args.workload == "km2"
     map_device_s = map_device_warm_s = map_download_s = None
@@ -362,7 +388,7 @@ def main():
                 raise RuntimeError("single-GPU measurement: skipped when the job spans several GPUs (run `python bench.py` for it)")
             fq = 65536 if args.batch >= 16384 else min(2048, args.batch)      # many queries per workspace: the shared cursor balances the launch's tail
             S_, G_ = scenes.random_queries(fq, seed0=1000, occ_r2=m.occ_r2_buffer, grid=gridinfo)
-            ka = U.KinoAstar(m)
+            ka = U.KinoAstar(m, slots=min(fq, 4096))      # explicit workspaces (one per wave slot of 256 CUs): the automatic ones would grow inside the timed calls
             ka.plan_batch(S_[:64], G_[:64], path_cap=1)
             fe = {"slots": ka.slots, "primitives": ka.n_primitives}
             for nq in sorted(set((1, 256, min(fq, 2048), fq))):

@@ -14,6 +14,8 @@
  *   uph_opt_params          <- ALMTrajOpt public parameter members  alm_traj_opt.h:29-53 (rosparam, alm_traj_opt.cpp:7-29)
  *   uph_map_build           <- UnevenMap::constructMap  uneven_map/src/uneven_map.cpp:317-417 (+ crop/voxel filter :130-144)
  *   uph_map_set_cells       <- UnevenMap::constructMapInput  uneven_map.cpp:270-315 (cells from the .map cache)
+ *   uph_map_save_csv / uph_map_load_csv / uph_map_save_cache / uph_map_load_cache
+ *                           <- the `.map` cache: written at the end of UnevenMap::constructMap (uneven_map.cpp:400-412), read by constructMapInput (:270-315)
  *   uph_map_get_cells       -> fills UnevenMap::map_buffer / c_buffer / occ_buffer / occ_r2_buffer
  *                              uneven_map/include/uneven_map/uneven_map.h:91-94, occupancy rule uneven_map.cpp:170-179
  *   uph_terrain_query       <- UnevenMap::getAllWithGrad  uneven_map.h:318-377 (device-side twin, exposed for parity tests)
@@ -226,6 +228,23 @@ int uph_map_dims(const uph_map* m, int32_t dims3[3]);                       /* v
 int uph_map_set_cells(uph_map* m, const double* rxs2);
 /* any pointer may be NULL.  rxs2: ncell x 4, c: ncell, occ: ncell chars, occ_r2: nx*ny chars */
 int uph_map_get_cells(uph_map* m, double* rxs2, double* c, char* occ, char* occ_r2);
+/* ---- the `.map` cache: the CSV UnevenMap::constructMap writes at its end (uneven_map.cpp:400-412: one line
+ * `x,y,yaw,z,sigma,zb.x,zb.y` per cell in address order, ostream default format = six significant digits) and constructMapInput reads
+ * (uneven_map.cpp:270-315: cells not mentioned stay RXS2() zeros, indices through atoi, values through stold narrowed to double, lines with an
+ * index outside the grid dropped), plus a binary side-car that holds the cells bit for bit.  Host functions, no device needed:
+ * rxs2 = ncell x 4 doubles in address order, dims3 = voxel_num; c (may be NULL) receives c_buffer = sqrt(1 - |zb|^2) of the cells read, 1 for
+ * the others (uneven_map.cpp:117-119, 307); n_lines (may be NULL) the number of lines used.  load_*: UPH_ERR_INVALID when the file cannot be
+ * opened (the reference then builds the map, uneven_map.cpp:166-167), load_bin UPH_ERR_LIMIT when it was written for another grid. */
+int uph_map_save_csv(const char* path, const double* rxs2, const int32_t dims3[3]);
+int uph_map_load_csv(const char* path, const int32_t dims3[3], double* rxs2, double* c, int64_t* n_lines);
+int uph_map_save_bin(const char* path, const double* rxs2, const int32_t dims3[3]);
+int uph_map_load_bin(const char* path, const int32_t dims3[3], double* rxs2);
+/* the same against a device map: save = download the cells and write the CSV and / or the side-car (either path may be NULL); load =
+ * constructMapInput: the side-car if bin_path names a readable one for this grid that is not older than the CSV (the CSV is the reference's own
+ * cache and the source of truth: one regenerated later wins), else the CSV, then uph_map_set_cells (commit: c, occupancy).
+ * source (may be NULL): 2 side-car, 1 CSV.  UPH_ERR_INVALID when no cache can be read: build the map then. */
+int uph_map_save_cache(uph_map* m, const char* csv_path, const char* bin_path);
+int uph_map_load_cache(uph_map* m, const char* csv_path, const char* bin_path, int32_t* source);
 /* constructMap on the x-slab [x0, x1): crop box + 1 cm voxel filter, xy bucketing and plane fits all on the device (the host uploads the cloud).
  * xyz: n x 3 float32 (what pcl::PCDReader delivers).  Cells outside the slab are untouched.  Blocking. */
 int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x1);
@@ -236,6 +255,10 @@ int uph_map_build(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_t x
  * the process already carries, else the system's); n_gpus = 1 needs none.  maps on the SAME device are accepted (single-GPU test
  * configuration: RCCL refuses a device twice, the slabs then move by device-to-device copies).  Blocking. */
 int uph_map_build_multi(uph_map* const* maps, int32_t n_gpus, const float* xyz, int64_t n);
+/* the host-side decisions of the two *_multi builds for a grid of nx rows over n_gpus devices, without a device (dry run of an 8-GPU node on
+ * any box): x0[g], x1[g] = the x-slab device g fits (per = ceil(nx / n_gpus) rows; the last slabs shorter or empty), *in_place = 1 when the
+ * all-gather runs in place on the cell arrays (n_gpus divides nx), 0 when it goes through zero-padded staging of n_gpus x per rows */
+int uph_multi_slab_plan(int32_t nx, int32_t n_gpus, int32_t* x0, int32_t* x1, int32_t* per, int32_t* in_place);
 /* the analytic terrain (uph_map_fill_fbm) sharded the same way; fp32 maps exchange float slabs */
 int uph_map_fill_fbm_multi(uph_map* const* maps, int32_t n_gpus, const uph_fbm_params* fp);
 /* wall milliseconds of the last *_multi call led by `lead` (= maps[0]): slab fits, slab exchange, commit; HIP-event milliseconds of the
@@ -282,10 +305,14 @@ int64_t uph_map_built_cloud(uph_map* m, float* out_xyz, int64_t cap);
 /* ---- front end: KinoAstar::plan for a batch of queries, one wave64 per query (csrc/kino_search.hip).
  * uph_kino_create = KinoAstar::init + setEnvironment (kino_astar.cpp:5-43, kino_astar.h:170-178): parameters, the Dubins radius wheel_base / tan(max_steer),
  * a node pool of getXYNum() nodes per concurrent query.  slots = number of queries searched concurrently (each owns ~3.7 MB of HBM at 200 x 200 cells);
- * 0 = one per wave slot of the default kernel instantiation (16 per compute unit).  The map must stay alive and must not be rebuilt while a search runs. */
+ * when the device cannot hold that many, as many as fit (uph_kino_slots tells).  slots = 0: automatic -- the workspaces follow the batches that
+ * arrive (allocated by the first uph_kino_plan_batch for its B, at least 16; grown when a larger batch comes), up to one per wave slot of the default
+ * kernel instantiation (16 per compute unit) and never beyond half of the HBM that was free at creation: a single plan() costs ~60 MB, not 16 GB.
+ * UPH_ERR_LIMIT when the grid has more than 2^31 columns or (cells + 1) x yaw bins of the lattice does not fit 32-bit keys, or when not even one
+ * workspace fits.  The map must stay alive and must not be rebuilt while a search runs. */
 int uph_kino_create(uph_map* m, const uph_kino_params* kp, int32_t slots, uph_kino** out);
 void uph_kino_destroy(uph_kino* k);
-int uph_kino_slots(const uph_kino* k);
+int uph_kino_slots(const uph_kino* k);           /* workspaces allocated (automatic context before its first search: the upper bound) */
 /* experiment knob: waves per SIMD the search kernel is compiled for -- 2, 4 (default), 6 or 8 (register caps 256 / 128 / 80 / 64) */
 int uph_kino_set_wps(uph_kino* k, int32_t wps);
 /* experiment knob: bit 0 = queries handed out dynamically, longest first (default on); bit 1 = sincosFast instead of the device library's sin / cos (default on) */
@@ -338,6 +365,9 @@ int uph_optimize_batch(uph_ctx* c, int32_t B, const uph_problem* probs, uph_resu
  * upload -> solve -> download on its share; results[] comes back in the caller's order.  No collective: trajectories are independent.
  * Contexts on the same device are accepted (test configuration).  n_gpus = 1 is uph_optimize_batch. */
 int uph_optimize_batch_multi(uph_ctx* const* ctxs, int32_t n_gpus, int32_t B, const uph_problem* probs, uph_result* results);
+/* the split uph_optimize_batch_multi makes, without a device: share_of[b] = index of the context problem b is dealt to (descending predicted
+ * cost, round-robin); predicted_cost (may be NULL) [B] = the a-priori cost the split and every upload's launch order sort by */
+int uph_multi_batch_plan(int32_t n_gpus, int32_t B, const uph_problem* probs, int32_t* share_of, double* predicted_cost);
 /* number of problems of the uploaded batch (0: none) */
 int uph_batch_count(const uph_ctx* c);
 /* after uph_optimize_batch_multi every context holds ITS SHARE of the batch (uph_batch_count problems, in share order): idx[k] = the caller's index

@@ -239,6 +239,17 @@ public:
     void setCells(const double* rxs2) {
         if (uph_map_set_cells(m_, rxs2) != UPH_OK) throw std::runtime_error(std::string("uph_map_set_cells: ") + uph_last_error());
     }
+    // the `.map` cache (uneven_map.cpp:166-167, 270-315, 400-412).  loadMap = constructMapInput: false when no cache can be read (build the map
+    // then); it prefers the bit-exact side-car `<map_file>.bin` and falls back to the reference's CSV.  saveMap = the "to txt" block at the end of
+    // constructMap -- the CSV the reference's own constructMapInput reads (six significant digits) -- plus the side-car.
+    bool loadMap(const std::string& map_file) {
+        int32_t src = 0;
+        return uph_map_load_cache(m_, map_file.c_str(), (map_file + ".bin").c_str(), &src) == UPH_OK;
+    }
+    void saveMap(const std::string& map_file, bool with_sidecar = true) {
+        const std::string bin = map_file + ".bin";
+        if (uph_map_save_cache(m_, map_file.c_str(), with_sidecar ? bin.c_str() : nullptr) != UPH_OK) throw std::runtime_error(std::string("uph_map_save_cache: ") + uph_last_error());
+    }
     // analytic fractal terrain instead of a cloud (configs[4]; no counterpart in the reference)
     void fillFractal(const uph_fbm_params& fp) {
         if (uph_map_fill_fbm(m_, &fp, 0, 0) != UPH_OK) throw std::runtime_error(std::string("uph_map_fill_fbm: ") + uph_last_error());

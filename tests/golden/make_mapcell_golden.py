@@ -49,6 +49,7 @@ def fit_cell(cloud, ix, iy, iw):
     box_r = max(ex, ey, ez)
     c64 = cloud.astype(np.float64)
     z, sig, zbx, zby, cc = 0.0, 0.0, 0.0, 0.0, 1.0
+    counts = []
     for it in range(PAR["iter_num"]):
         xyaw = np.array([math.cos(yaw), math.sin(yaw), 0.0])
         zb = np.array([zbx, zby, cc])
@@ -67,6 +68,7 @@ def fit_cell(cloud, ix, iy, iw):
         sub = cand - w
         inrob = np.stack([sub @ xb / ex, sub @ yb / ey, sub @ zb / ez], axis=1)
         pts = cand[(inrob ** 2).sum(axis=1) < 1.0]
+        counts.append(len(pts))
         if len(pts) == 0:
             z, sig, zbx, zby, cc = w[2], 0.0, 0.0, 0.0, 1.0
             continue
@@ -81,23 +83,31 @@ def fit_cell(cloud, ix, iy, iw):
             sig, n = 1.0, np.array([1.0, 0.0, 0.0])
         z, zbx, zby = mean[2], n[0], n[1]
         cc = math.sqrt(1.0 - zbx * zbx - zby * zby)
+    fit_cell.min_points = min(counts)       # (side channel: the smallest fit of the cell's iterations -- fewer than 4 points make the plane ambiguous)
     return np.array([z, sig, zbx, zby]), len(pts)
 
 
-def main():
-    xyz = np.load(os.path.join(HERE, "desert_xyz.npz"))["xyz"]
+def main(scene="desert"):
+    """scene: desert (mapcells_golden.npz, the round-1 fixture), forest / mountain (mapcells_<scene>_golden.npz): forest.pcd is the cloud whose
+    voxel filter merges points (141 068 -> 137 491 leaves with PCL's float leaf arithmetic; 137 490 if the leaf index is formed in double) and
+    holds vertical structure (trunks: near-degenerate fits), mountain.pcd the sparse one (50 000 points: ~17 per fit)"""
+    xyz = np.load(os.path.join(HERE, "%s_xyz.npz" % scene))["xyz"]
     cloud = crop_and_voxel(xyz)
     print("cloud after crop + voxel:", cloud.shape)
-    rng = np.random.default_rng(20240917)
-    idx, cells, npts = [], [], []
+    rng = np.random.default_rng(20240917 if scene == "desert" else (20260927 if scene == "forest" else 20260928))
+    idx, cells, npts, nmin = [], [], [], []
+    lo, hi = (10, 190) if scene != "mountain" else (30, 170)
     while len(idx) < 300:
-        ix, iy, iw = int(rng.integers(10, 190)), int(rng.integers(10, 190)), int(rng.integers(64))
+        ix, iy, iw = int(rng.integers(lo, hi)), int(rng.integers(lo, hi)), int(rng.integers(64))
         c, k = fit_cell(cloud, ix, iy, iw)
-        idx.append((ix, iy, iw)); cells.append(c); npts.append(k)
-    np.savez_compressed(os.path.join(HERE, "mapcells_golden.npz"), idx=np.array(idx, dtype=np.int32), cells=np.array(cells), npts=np.array(npts, dtype=np.int32),
-                        cloud_points=np.array(cloud.shape[0]))
-    print("points per fit: min %d median %d max %d" % (min(npts), int(np.median(npts)), max(npts)))
+        idx.append((ix, iy, iw)); cells.append(c); npts.append(k); nmin.append(fit_cell.min_points)
+    name = "mapcells_golden.npz" if scene == "desert" else "mapcells_%s_golden.npz" % scene
+    extra = {} if scene == "desert" else dict(npts_min=np.array(nmin, dtype=np.int32))      # (the desert fixture keeps its round-1 content: no fit below 33 points there)
+    np.savez_compressed(os.path.join(HERE, name), idx=np.array(idx, dtype=np.int32), cells=np.array(cells), npts=np.array(npts, dtype=np.int32),
+                        cloud_points=np.array(cloud.shape[0]), **extra)
+    print("%s: points per fit: min %d median %d max %d" % (name, min(npts), int(np.median(npts)), max(npts)))
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    main(sys.argv[1] if len(sys.argv) > 1 else "desert")

@@ -142,6 +142,103 @@ def test_map_csv_cross_reads_and_binary_sidecar(tmp_path, oracle):
         HostGridView.read_map_binary(p3, 2.0, 1.0)
 
 
+CSV_CPP = r"""
+// the `.map` cache from the reference host's own language: what UnevenMap::constructMap / constructMapInput would call after the swap
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "uneven_hip.h"
+int main(int argc, char** argv) {
+    // argv: in.map  out.map  out.bin  nx ny nyaw     -- read the CSV as constructMapInput does, write it back, write + re-read the side-car
+    const int32_t d[3] = {atoi(argv[4]), atoi(argv[5]), atoi(argv[6])};
+    const size_t ncell = (size_t)d[0] * d[1] * d[2];
+    std::vector<double> cells(4 * ncell), c(ncell), back(4 * ncell);
+    int64_t lines = 0;
+    if (uph_map_load_csv(argv[1], d, cells.data(), c.data(), &lines) != UPH_OK) { std::printf("load failed: %s\n", uph_last_error()); return 2; }
+    if (uph_map_save_csv(argv[2], cells.data(), d) != UPH_OK || uph_map_save_bin(argv[3], cells.data(), d) != UPH_OK) return 3;
+    if (uph_map_load_bin(argv[3], d, back.data()) != UPH_OK) return 4;
+    for (size_t i = 0; i < 4 * ncell; i++) if (back[i] != cells[i]) return 5;
+    const int32_t other[3] = {d[0] + 1, d[1], d[2]};
+    if (uph_map_load_bin(argv[3], other, back.data()) != UPH_ERR_LIMIT) return 6;
+    if (uph_map_load_csv("/nonexistent/dir/x.map", d, back.data(), nullptr, nullptr) != UPH_ERR_INVALID) return 7;      // -> the caller builds the map
+    std::printf("%lld lines\n", (long long)lines);
+    return 0;
+}
+"""
+
+
+def test_map_cache_in_the_c_abi_against_the_oracle_and_the_mirror(tmp_path, oracle):
+    """VERDICT r04 missing 3 (N3 in the host's language): uph_map_save_csv / uph_map_load_csv / uph_map_save_bin / uph_map_load_bin (host functions of
+    the C-ABI, csrc/map_io_host.cpp) against the oracle's restatement of uneven_map.cpp:270-315, 400-412 and the Python mirror -- same text
+    both ways, same doubles after the stold-then-double parse, cells the file does not mention stay RXS2() zeros with c = 1, lines with an
+    index outside the grid dropped, any line order, side-car bit exact; exercised from ctypes AND from a C++ program"""
+    import ctypes as C
+    import subprocess
+    import uneven_planner_amd as U
+    from uneven_planner_amd.host_map import HostGridView
+    L = U._lib.load()
+    OL = oracle.lib()
+    rng = np.random.default_rng(9)
+    g = oracle.OracleGrid(size_x=1.0, size_y=1.0)
+    dims = (C.c_int32 * 3)(*[int(v) for v in g.dims])
+    cells = np.column_stack([rng.normal(size=g.ncell) * 10.0 ** rng.integers(-7, 3, g.ncell), rng.uniform(0, 0.2, g.ncell), rng.uniform(-0.3, 0.3, g.ncell), rng.uniform(-0.3, 0.3, g.ncell)])
+    cells[:7, 0] = [0.0, -0.0, 1e-5, 123456.5, -1e-310, 0.1, 1.0 / 3.0]             # %g corner cases: exponent switch, rounding up a digit, a denormal
+    g.set_cells(cells)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    # 1. the three writers (reference ostream form in the oracle, the Python mirror's "%.6g", the C-ABI's) produce the same file
+    p_or, p_py, p_c = (str(tmp_path / n) for n in ("oracle.map", "mirror.map", "cabi.map"))
+    assert OL.orc_map_write_csv(g.h, p_or.encode()) == 0
+    HostGridView(cells, 1.0, 1.0).write_map_file(p_py)
+    assert L.uph_map_save_csv(p_c.encode(), dp(np.ascontiguousarray(cells)), dims) == 0
+    assert open(p_c).read() == open(p_or).read() == open(p_py).read()
+    # 2. the three readers land on the same doubles (two roundings: stold, then double)
+    got, cbuf, nl = np.full((g.ncell, 4), 7.0), np.zeros(g.ncell), C.c_int64(0)
+    assert L.uph_map_load_csv(p_or.encode(), dims, dp(got), dp(cbuf), C.byref(nl)) == 0 and nl.value == g.ncell
+    g2 = oracle.OracleGrid(size_x=1.0, size_y=1.0)
+    assert OL.orc_map_read_csv(g2.h, p_c.encode()) == 0
+    want, want_c = g2.get_cells()[0], g2.get_cells()[1]
+    assert np.array_equal(got, want) and np.array_equal(got, HostGridView.read_map_file(p_c, 1.0, 1.0).cells.reshape(-1, 4))
+    assert np.array_equal(cbuf, want_c)
+    assert np.abs(got - cells).max() <= 5e-6 * np.abs(cells).max() and not np.array_equal(got, cells)          # six significant digits
+    # 3. a partial, shuffled file with out-of-range and short lines: untouched cells stay zero / c = 1, later lines win
+    lines = open(p_c).read().splitlines()
+    keep = [lines[i] for i in rng.permutation(len(lines))[: len(lines) // 3]]
+    keep += ["%d,0,0,1,2,0.1,0.2" % g.dims[0], "-1,0,0,1,2,0.1,0.2", "0,0,%d,1,2,0.1,0.2" % g.dims[2], "3,4", "", keep[0].rsplit(",", 4)[0] + ",9.5,0.125,0.25,-0.5"]
+    p_part = str(tmp_path / "partial.map")
+    open(p_part, "w").write("\n".join(keep) + "\n")
+    got2, c2 = np.full((g.ncell, 4), 7.0), np.zeros(g.ncell)
+    assert L.uph_map_load_csv(p_part.encode(), dims, dp(got2), dp(c2), C.byref(nl)) == 0
+    g3 = oracle.OracleGrid(size_x=1.0, size_y=1.0)
+    assert OL.orc_map_read_csv(g3.h, p_part.encode()) == 0
+    assert np.array_equal(got2, g3.get_cells()[0]) and np.array_equal(c2, g3.get_cells()[1])
+    assert nl.value == len(lines) // 3 + 1 and (got2 == 0.0).all(axis=1).sum() >= g.ncell - len(lines) // 3 - 1
+    x0, y0, w0 = (int(v) for v in keep[0].split(",")[:3])
+    a0 = (x0 * int(g.dims[1]) + y0) * int(g.dims[2]) + w0
+    assert list(got2[a0]) == [9.5, 0.125, 0.25, -0.5] and c2[a0] == np.sqrt(1.0 - 0.25 ** 2 - 0.5 ** 2)
+    # 4. side-car: bit exact, same bytes as the mirror's, refuses another grid
+    p_b, p_bpy = str(tmp_path / "cabi.map.bin"), str(tmp_path / "mirror.map.bin")
+    assert L.uph_map_save_bin(p_b.encode(), dp(np.ascontiguousarray(cells)), dims) == 0
+    HostGridView(cells, 1.0, 1.0).write_map_binary(p_bpy)
+    assert open(p_b, "rb").read() == open(p_bpy, "rb").read()
+    back = np.zeros((g.ncell, 4))
+    assert L.uph_map_load_bin(p_b.encode(), dims, dp(back)) == 0 and np.array_equal(back, cells) and np.array_equal(np.signbit(back), np.signbit(cells))
+    assert L.uph_map_load_bin(p_b.encode(), (C.c_int32 * 3)(int(g.dims[0]), int(g.dims[1]) + 1, int(g.dims[2])), dp(back)) == -4      # UPH_ERR_LIMIT
+    assert L.uph_map_load_bin(p_c.encode(), dims, dp(back)) == -1                          # a CSV is not a side-car
+    # 5. the same entry points from C++ (the language of the reference host)
+    src = tmp_path / "csv_consumer.cpp"
+    src.write_text(CSV_CPP)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "uneven_planner_amd")
+    exe = str(tmp_path / "csv_consumer")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", exe, "-L", libdir, "-lunevenhip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out_map, out_bin = str(tmp_path / "cpp.map"), str(tmp_path / "cpp.map.bin")
+    r = subprocess.run([exe, p_or, out_map, out_bin] + [str(int(v)) for v in g.dims], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout)
+    assert open(out_map).read() == open(p_or).read()                  # six-digit text is a fixed point of read -> write
+    assert np.array_equal(HostGridView.read_map_binary(out_bin, 1.0, 1.0).cells.reshape(-1, 4), got)
+
+
 def test_tile_rows_and_owner_routing_cover_every_problem():
     """SURVEY.md 8e row 3, host side: x-slab tiles with a halo and the owner rule -- every problem has exactly one owner and lies inside
     the owner's tile with room to spare when the halo exceeds the longest local goal"""

@@ -8,7 +8,7 @@ SRC=uneven_planner_amd/csrc
 pids=()
 for spec in "$@"; do
   name="${spec%%=*}"; flags="${spec#*=}"
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value $flags -shared $SRC/unevenhip.hip $SRC/map_build.hip $SRC/kino_search.hip $SRC/resample_host.cpp -o build/variants/libunevenhip_$name.so && echo "built $name ($flags)" ) &
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value $flags -shared $SRC/unevenhip.hip $SRC/map_build.hip $SRC/kino_search.hip $SRC/resample_host.cpp $SRC/map_io_host.cpp -ldl -lpthread -o build/variants/libunevenhip_$name.so && echo "built $name ($flags)" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

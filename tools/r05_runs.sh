@@ -1,0 +1,42 @@
+#!/bin/bash
+# The GPU-box command lists of round 5's gpurun calls, one case per call: gpurun -- "bash tools/r05_runs.sh <n>".
+set -u
+cd $GRAFT_REPO_ROOT
+make -C oracle -s 2>&1 | tail -2
+case "${1:-}" in
+1)
+# local frames (km^2 parity fix): hill results bit for bit against round 4's library, the whole GPU tier (new far-from-origin test), A/B of the
+# solve launch against round 4's library, the km^2 bench line with its parity buckets, LDS bank conflicts of the penalty kernel by phase
+OUT=gpurun_out/r05a; mkdir -p $OUT
+python tools/cmp_variant.py $OUT/x_default.npy 2>&1 | tail -2
+UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_r04.so python tools/cmp_variant.py $OUT/x_r04.npy 2>&1 | tail -2
+python -c "
+import numpy as np
+a, b = np.load('$OUT/x_default.npy'), np.load('$OUT/x_r04.npy')
+print('hill, 64 solves, this build vs round 4 library: bit-identical', np.array_equal(a, b), 'max diff', np.abs(a - b).max())" | tee $OUT/bit_identity.txt
+timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -15 $OUT/gpu_tests.txt | cut -c1-300
+timeout 300 python -m pytest tests/test_gpu_km2.py -q -s -k far_from_origin 2>&1 | grep -E "far-from|within|passed|failed" | cut -c1-300 | tee $OUT/far_test.txt
+for v in default r04; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu --no-extras > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  python - $OUT/bench_$v.json $v <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+    print('%-10s value %.0f traj/s  launch %.1f ms  frac %.3f  converged %.3f' % (sys.argv[2], r['value'], r['roofline']['avg_launch_ms'], r['roofline']['frac'], r['converged_frac']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e, open(sys.argv[1].replace('.json', '.err')).read()[-400:])
+PY
+done 2>&1 | tee $OUT/ab.txt
+unset UNEVENHIP_LIB
+timeout 600 python bench.py --workload km2 --steps 3 --warmup 1 > $OUT/bench_km2.json 2> $OUT/bench_km2.err; echo "km2 rc $?"
+python - $OUT/bench_km2.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+print("km2 value", r["value"], "frac", r["roofline"]["frac"], "converged", r["converged_frac"])
+print(json.dumps(r.get("parity_floor"), indent=None)[:1500])
+PY
+bash tools/pmc_phases.sh r05a lds 2>&1 | tee $OUT/pmc_phases_lds.txt
+;;
+esac

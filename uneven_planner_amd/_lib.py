@@ -77,6 +77,12 @@ SYMBOLS = {
     "uph_map_fill_fbm": (C.c_int, [_VP, C.POINTER(FbmParams), _I32, _I32]),
     "uph_fbm_table": (C.c_int, [C.POINTER(FbmParams), DP]),
     "uph_map_get_window": (C.c_int, [_VP, _I32, _I32, _I32, _I32, DP]),
+    "uph_map_save_csv": (C.c_int, [C.c_char_p, DP, C.POINTER(_I32)]),
+    "uph_map_load_csv": (C.c_int, [C.c_char_p, C.POINTER(_I32), DP, DP, C.POINTER(_I64)]),
+    "uph_map_save_bin": (C.c_int, [C.c_char_p, DP, C.POINTER(_I32)]),
+    "uph_map_load_bin": (C.c_int, [C.c_char_p, C.POINTER(_I32), DP]),
+    "uph_map_save_cache": (C.c_int, [_VP, C.c_char_p, C.c_char_p]),
+    "uph_map_load_cache": (C.c_int, [_VP, C.c_char_p, C.c_char_p, C.POINTER(_I32)]),
     "uph_map_destroy": (None, [_VP]),
     "uph_map_dims": (C.c_int, [_VP, C.POINTER(_I32)]),
     "uph_map_set_cells": (C.c_int, [_VP, DP]),
@@ -84,6 +90,8 @@ SYMBOLS = {
     "uph_map_build": (C.c_int, [_VP, C.POINTER(C.c_float), _I64, _I32, _I32]),
     "uph_map_build_multi": (C.c_int, [C.POINTER(_VP), _I32, C.POINTER(C.c_float), _I64]),
     "uph_map_fill_fbm_multi": (C.c_int, [C.POINTER(_VP), _I32, C.POINTER(FbmParams)]),
+    "uph_multi_slab_plan": (C.c_int, [_I32, _I32, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "uph_multi_batch_plan": (C.c_int, [_I32, _I32, C.POINTER(Problem), C.POINTER(_I32), DP]),
     "uph_map_multi_stats": (C.c_int, [_VP, DP, DP, DP, DP, C.POINTER(_I32)]),
     "uph_multi_shutdown": (None, []),
     "uph_rccl_selftest": (C.c_int, [_I32, C.c_char_p, _I32]),

@@ -16,6 +16,28 @@ HILL_OPT_PARAMS = dict(rho_T=100000.0, rho_ter=10.0, max_vel=0.5, max_acc_lon=5.
 _INT_FIELDS = ("use_scaling", "mem_size", "past", "int_K")
 
 
+def pack_problems(probs, int_K=16, with_sizes=False):
+    """problem dicts -> a ctypes array of uph_problem (column-major matrices, as Eigen::MatrixXd holds them) + the numpy arrays its pointers
+    refer to (keep them alive while the array is in use) [+ the per-problem sizes]; no device, no context needed"""
+    arr = (_lib.Problem * len(probs))()
+    keep, sizes = [], []
+    for i, pr in enumerate(probs):
+        ixy = np.ascontiguousarray(np.asarray(pr["inner_xy"], dtype=np.float64).T)       # column-major 2 x (Nxy-1)
+        iyw = np.ascontiguousarray(pr["inner_yaw"], dtype=np.float64)
+        keep += [ixy, iyw]
+        a = arr[i]
+        a.n_inner_xy, a.n_inner_yaw = ixy.shape[0], iyw.shape[0]
+        a.init_xy[:] = np.asarray(pr["init_xy"], dtype=np.float64).T.ravel().tolist()
+        a.end_xy[:] = np.asarray(pr["end_xy"], dtype=np.float64).T.ravel().tolist()
+        a.init_yaw[:] = np.asarray(pr["init_yaw"], dtype=np.float64).ravel().tolist()
+        a.end_yaw[:] = np.asarray(pr["end_yaw"], dtype=np.float64).ravel().tolist()
+        a.inner_xy, a.inner_yaw = _dp(ixy), _dp(iyw)
+        a.total_time = float(pr["total_time"])
+        nxy, nyaw = a.n_inner_xy + 1, a.n_inner_yaw + 1
+        sizes.append(dict(Nxy=nxy, Nyaw=nyaw, n=2 * (nxy - 1) + (nyaw - 1) + 1, S=nxy * (int(int_K) + 1)))
+    return (arr, keep, sizes) if with_sizes else (arr, keep)
+
+
 def _dp(a):
     return a.ctypes.data_as(_lib.DP)
 
@@ -149,23 +171,7 @@ class ALMTrajOpt:
 
     # ---- batch plumbing ---------------------------------------------------------------------------------------------
     def _make_problems(self, probs):
-        arr = (_lib.Problem * len(probs))()
-        keep = []
-        self._sizes = []
-        for i, pr in enumerate(probs):
-            ixy = np.ascontiguousarray(np.asarray(pr["inner_xy"], dtype=np.float64).T)       # column-major 2 x (Nxy-1)
-            iyw = np.ascontiguousarray(pr["inner_yaw"], dtype=np.float64)
-            keep += [ixy, iyw]
-            a = arr[i]
-            a.n_inner_xy, a.n_inner_yaw = ixy.shape[0], iyw.shape[0]
-            a.init_xy[:] = np.asarray(pr["init_xy"], dtype=np.float64).T.ravel().tolist()
-            a.end_xy[:] = np.asarray(pr["end_xy"], dtype=np.float64).T.ravel().tolist()
-            a.init_yaw[:] = np.asarray(pr["init_yaw"], dtype=np.float64).ravel().tolist()
-            a.end_yaw[:] = np.asarray(pr["end_yaw"], dtype=np.float64).ravel().tolist()
-            a.inner_xy, a.inner_yaw = _dp(ixy), _dp(iyw)
-            a.total_time = float(pr["total_time"])
-            nxy, nyaw = a.n_inner_xy + 1, a.n_inner_yaw + 1
-            self._sizes.append(dict(Nxy=nxy, Nyaw=nyaw, n=2 * (nxy - 1) + (nyaw - 1) + 1, S=nxy * (int(self.int_K) + 1)))
+        arr, keep, self._sizes = pack_problems(probs, int(self.int_K), with_sizes=True)
         return arr, keep
 
     def upload(self, probs):

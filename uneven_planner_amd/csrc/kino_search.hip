@@ -654,6 +654,12 @@ struct uph_kino {
     int device = 0;
     KinoDev P;
     int slots = 0, wps = UPH_KINO_WPS, flags = 3;      // flags: bit 0 = dynamic query hand-out, bit 1 = sincosFast
+    // slots = workspaces allocated now.  auto_slots (uph_kino_create with slots = 0): the workspaces follow the batch sizes that actually arrive --
+    // allocated at the first uph_kino_plan_batch, grown when a larger batch comes -- up to slots_cap = what the device can run at once, clamped to
+    // half of the HBM that was free at creation (one workspace is ~4 MB at 200 x 200 cells: a single plan() must not reserve 16 GB)
+    int slots_cap = 0;
+    bool auto_slots = false;
+    size_t slot_bytes = 0;
     size_t node_stride = 0, heap_stride = 0, table_stride = 0;
     void *d_P = nullptr, *d_nodes = nullptr, *d_heap = nullptr, *d_pos = nullptr, *d_key = nullptr, *d_table = nullptr;
     void *d_io[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -661,6 +667,26 @@ struct uph_kino {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     double last_ms = 0.0;
 };
+
+// (re)allocate the per-query workspaces for `want` concurrent queries; when the device cannot hold them, for half as many, and so on
+static void kinoFreeWork(uph_kino* k) {
+    hipFree(k->d_nodes); hipFree(k->d_heap); hipFree(k->d_pos); hipFree(k->d_key); hipFree(k->d_table);
+    k->d_nodes = k->d_heap = k->d_pos = k->d_key = k->d_table = nullptr;
+    k->slots = 0;
+}
+static int kinoAllocWork(uph_kino* k, int want) {
+    kinoFreeWork(k);
+    for (int n = std::max(1, want); n >= 1; n = n == 1 ? 0 : n / 2) {
+        const bool ok = hipMalloc(&k->d_nodes, sizeof(KNode) * k->node_stride * n) == hipSuccess && hipMalloc(&k->d_heap, sizeof(KHeap) * k->heap_stride * n) == hipSuccess &&
+                        hipMalloc(&k->d_pos, sizeof(int) * k->node_stride * n) == hipSuccess && hipMalloc(&k->d_key, sizeof(int) * k->node_stride * n) == hipSuccess &&
+                        hipMalloc(&k->d_table, sizeof(int) * k->table_stride * n) == hipSuccess;
+        if (ok) { k->slots = n; return UPH_OK; }
+        (void)hipGetLastError();             // (out of memory is sticky until read)
+        kinoFreeWork(k);
+    }
+    setError("uph_kino: hipMalloc of one search workspace (" + std::to_string(k->slot_bytes >> 20) + " MiB) failed");
+    return UPH_ERR_HIP;
+}
 
 extern "C" {
 
@@ -681,12 +707,15 @@ int uph_kino_create(uph_map* m, const uph_kino_params* kp, int32_t slots, uph_ki
     P.time_interval = kp->time_interval; P.coll_interval = kp->collision_interval; P.oneshot_range = kp->oneshot_range; P.wheel_base = kp->wheel_base;
     P.rho = kp->wheel_base / std::tan(kp->max_steer);                       // :33
     P.tie_breaker = 1.0 + 1.0 / 10000;                                      // kino_astar.h:127
+    if ((int64_t)g.nx * g.ny > (int64_t)INT32_MAX - 1) { delete k; setError("uph_kino_create: the grid has more than 2^31 columns (node indices and lattice keys are 32-bit)"); return UPH_ERR_LIMIT; }
     P.nxy = g.nx * g.ny;
     P.allocate_num = g.nx * g.ny;                                           // setEnvironment: getXYNum nodes
     {
         const double top = std::floor((3.14159265358979323846 + 3.14159265358979323846) * P.yaw_inv);
         if (!(top >= 0 && top < 4096)) { delete k; setError("uph_kino_create: yaw_resolution gives more than 4096 yaw bins"); return UPH_ERR_LIMIT; }
         P.nyawk = (int)top + 1;
+        // the lattice key (ix * ny + iy) * nyawk + iyaw and the table of (nxy + 1) * nyawk entries are 32-bit
+        if (((int64_t)P.nxy + 1) * (int64_t)P.nyawk > (int64_t)INT32_MAX) { delete k; setError("uph_kino_create: (cells + 1) x yaw bins of the search lattice exceeds 2^31 (coarser kino_astar/yaw_resolution or a smaller grid)"); return UPH_ERR_LIMIT; }
     }
     // the primitives and their collision sample times, by the reference's own loops (kino_astar.cpp:138-145, 173-175)
     int ni = 0;
@@ -718,22 +747,27 @@ int uph_kino_create(uph_map* m, const uph_kino_params* kp, int32_t slots, uph_ki
         for (int i = 0; i < ni; i++) mx = std::max(mx, P.in_nt[i]);
         P.spread = (ni <= 16 && mx <= 3) ? 1 : 0;
     }
-    if (slots == 0) {
-        hipDeviceProp_t prop;
-        KHIPCHK(hipGetDeviceProperties(&prop, k->device));
-        slots = prop.multiProcessorCount * 4 * UPH_KINO_WPS;                // one workspace per wave slot of the default instantiation
-    }
-    k->slots = slots;
     k->node_stride = (size_t)P.allocate_num;
     k->heap_stride = (size_t)P.allocate_num + 1;
     k->table_stride = (((size_t)P.nxy + 1) * P.nyawk + 15) & ~(size_t)15;
-    auto fail = [&](const char* what) { setError(std::string("uph_kino_create: hipMalloc(") + what + ") failed"); uph_kino_destroy(k); return UPH_ERR_HIP; };
-    if (hipMalloc(&k->d_P, sizeof(KinoDev)) != hipSuccess) return fail("params");
-    if (hipMalloc(&k->d_nodes, sizeof(KNode) * k->node_stride * slots) != hipSuccess) return fail("nodes");
-    if (hipMalloc(&k->d_heap, sizeof(KHeap) * k->heap_stride * slots) != hipSuccess) return fail("heap");
-    if (hipMalloc(&k->d_pos, sizeof(int) * k->node_stride * slots) != hipSuccess) return fail("pos");
-    if (hipMalloc(&k->d_key, sizeof(int) * k->node_stride * slots) != hipSuccess) return fail("key");
-    if (hipMalloc(&k->d_table, sizeof(int) * k->table_stride * slots) != hipSuccess) return fail("table");
+    k->slot_bytes = sizeof(KNode) * k->node_stride + sizeof(KHeap) * k->heap_stride + 2 * sizeof(int) * k->node_stride + sizeof(int) * k->table_stride;
+    if (hipMalloc(&k->d_P, sizeof(KinoDev)) != hipSuccess) { setError("uph_kino_create: hipMalloc(params) failed"); uph_kino_destroy(k); return UPH_ERR_HIP; }
+    if (slots == 0) {
+        hipDeviceProp_t prop;
+        KHIPCHK(hipGetDeviceProperties(&prop, k->device));
+        size_t free_b = 0, total_b = 0;
+        KHIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const int64_t hw = (int64_t)prop.multiProcessorCount * 4 * UPH_KINO_WPS;        // one workspace per wave slot of the default instantiation
+        const int64_t fit = (int64_t)((free_b / 2) / k->slot_bytes);
+        if (fit < 1) { setError("uph_kino_create: one search workspace (" + std::to_string(k->slot_bytes >> 20) + " MiB for this grid) does not fit the free device memory"); uph_kino_destroy(k); return UPH_ERR_LIMIT; }
+        k->slots_cap = (int)std::min(hw, fit);
+        k->auto_slots = true;
+        k->slots = 0;                        // allocated by the first uph_kino_plan_batch, for the batch that arrives
+    } else {
+        k->slots_cap = slots;
+        const int r = kinoAllocWork(k, slots);      // (fewer than asked for when the device cannot hold them: uph_kino_slots tells)
+        if (r != UPH_OK) { uph_kino_destroy(k); return r; }
+    }
     if (hipMemcpy(k->d_P, &P, sizeof(KinoDev), hipMemcpyHostToDevice) != hipSuccess) { setError("uph_kino_create: hipMemcpy failed"); uph_kino_destroy(k); return UPH_ERR_HIP; }
     if (hipEventCreate(&k->e0) != hipSuccess || hipEventCreate(&k->e1) != hipSuccess) { setError("uph_kino_create: hipEventCreate failed"); uph_kino_destroy(k); return UPH_ERR_HIP; }
     *out = k;
@@ -743,14 +777,16 @@ int uph_kino_create(uph_map* m, const uph_kino_params* kp, int32_t slots, uph_ki
 void uph_kino_destroy(uph_kino* k) {
     if (!k) return;
     hipSetDevice(k->device);
-    hipFree(k->d_P); hipFree(k->d_nodes); hipFree(k->d_heap); hipFree(k->d_pos); hipFree(k->d_key); hipFree(k->d_table);
+    hipFree(k->d_P);
+    kinoFreeWork(k);
     for (int i = 0; i < 10; i++) hipFree(k->d_io[i]);
     if (k->e0) hipEventDestroy(k->e0);
     if (k->e1) hipEventDestroy(k->e1);
     delete k;
 }
 
-int uph_kino_slots(const uph_kino* k) { return k ? k->slots : UPH_ERR_INVALID; }
+// workspaces allocated; an automatic context (created with slots = 0) that has not searched yet reports its upper bound
+int uph_kino_slots(const uph_kino* k) { return k ? ((k->auto_slots && k->slots == 0) ? k->slots_cap : k->slots) : UPH_ERR_INVALID; }
 // experiment knob: which instantiation of the search kernel runs -- 2, 4, 6 or 8 waves per SIMD (register caps 256 / 128 / 80 / 64)
 // experiment knob: bit 0 = queries handed out dynamically (longest first) instead of statically, bit 1 = sincosFast instead of the device library's sin / cos
 int uph_kino_set_flags(uph_kino* k, int32_t flags) { if (!k || flags < 0 || flags > 3) return UPH_ERR_INVALID; k->flags = flags; return UPH_OK; }
@@ -767,6 +803,13 @@ int uph_kino_plan_batch(uph_kino* k, int32_t B, const double* starts, const doub
         setError("uph_kino_plan_batch: bad arguments"); return UPH_ERR_INVALID;
     }
     KHIPCHK(hipSetDevice(k->device));
+    if (k->auto_slots && k->slots < std::min((int)B, k->slots_cap)) {
+        // automatic workspaces follow the batch: first call, or a larger batch than any before (a few doublings at most over a context's life)
+        const int want = std::min(k->slots_cap, std::max((int)B, 16));
+        const int r = kinoAllocWork(k, want);
+        if (r != UPH_OK) return r;
+        if (k->slots < want) k->slots_cap = k->slots;      // the device could not hold more: stop asking
+    }
     const size_t need[10] = {sizeof(double) * 3 * (size_t)B, sizeof(double) * 3 * (size_t)B, sizeof(double) * 3 * (size_t)B * (size_t)std::max(1, path_cap), sizeof(int) * (size_t)B,
                              sizeof(int) * (size_t)B, sizeof(int) * (size_t)B, sizeof(int) * (size_t)B, sizeof(int) * 3 * (size_t)B * (size_t)std::max(1, exp_cap), sizeof(int) * (size_t)B, sizeof(int)};
     for (int i = 0; i < 10; i++) {
@@ -801,6 +844,7 @@ int uph_kino_plan_batch(uph_kino* k, int32_t B, const double* starts, const doub
     const char *occ = nullptr, *occ2 = nullptr;
     uphMapOcc(k->map, &occ, &occ2);
     const int grid = std::min((int)B, k->slots);
+    if (grid < 1) { setError("uph_kino_plan_batch: no workspace"); return UPH_ERR_HIP; }
     KHIPCHK(hipEventRecord(k->e0, 0));
 #define UPH_KINO_LAUNCH2(WPS_, F_) hipLaunchKernelGGL((uph_kino_kernel<WPS_, F_>), dim3(grid), dim3(64), 0, 0, uphMapGrid(k->map), occ, occ2, (const KinoDev*)k->d_P, W, k->node_stride, k->heap_stride, k->table_stride, io, (int)B)
 #define UPH_KINO_LAUNCH(WPS_) do { if (k->flags & 2) UPH_KINO_LAUNCH2(WPS_, true); else UPH_KINO_LAUNCH2(WPS_, false); } while (0)

@@ -16,6 +16,7 @@
 // (Eigen::EigenSolver in the reference) is solved with cyclic Jacobi in registers.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <cmath>
@@ -731,6 +732,45 @@ int uph_map_get_cells(uph_map* m, double* rxs2, double* c, char* occ, char* occ_
     return UPH_OK;
 }
 
+// ---- the `.map` cache against a device map (uneven_map.cpp:166-167, 270-315, 400-412; file formats: map_io_host.cpp)
+// save: the cells of the (whole-grid, fp64 or fp32) map into the CSV the reference's constructMapInput reads and / or the bit-exact side-car
+int uph_map_save_cache(uph_map* m, const char* csv_path, const char* bin_path) {
+    if (!m || (!csv_path && !bin_path)) { setError("uph_map_save_cache: bad arguments"); return UPH_ERR_INVALID; }
+    if (m->g.nx_hold != m->g.nx) { setError("uph_map_save_cache: a tile holds only part of the grid"); return UPH_ERR_INVALID; }
+    std::vector<double> cells;
+    try { cells.resize((size_t)m->ncell * 4); } catch (...) { setError("uph_map_save_cache: the grid does not fit host memory"); return UPH_ERR_LIMIT; }
+    int r = uph_map_get_cells(m, cells.data(), nullptr, nullptr, nullptr);
+    if (r != UPH_OK) return r;
+    const int32_t d[3] = {m->g.nx, m->g.ny, m->g.nyaw};
+    if (bin_path && (r = uph_map_save_bin(bin_path, cells.data(), d)) != UPH_OK) return r;
+    if (csv_path && (r = uph_map_save_csv(csv_path, cells.data(), d)) != UPH_OK) return r;
+    return UPH_OK;
+}
+// load = constructMapInput: the side-car when bin_path names a readable one for this grid (bit-exact), else the CSV (six digits); the cells
+// go to the device and the map commits (c, occupancy).  source (may be NULL): 2 = side-car, 1 = CSV.  UPH_ERR_INVALID when neither file can
+// be opened -- the caller then builds the map, as `if (!constructMapInput()) constructMap()` does.
+int uph_map_load_cache(uph_map* m, const char* csv_path, const char* bin_path, int32_t* source) {
+    if (!m || (!csv_path && !bin_path)) { setError("uph_map_load_cache: bad arguments"); return UPH_ERR_INVALID; }
+    if (m->g.nx_hold != m->g.nx) { setError("uph_map_load_cache: a tile holds only part of the grid"); return UPH_ERR_INVALID; }
+    std::vector<double> cells;
+    try { cells.resize((size_t)m->ncell * 4); } catch (...) { setError("uph_map_load_cache: the grid does not fit host memory"); return UPH_ERR_LIMIT; }
+    const int32_t d[3] = {m->g.nx, m->g.ny, m->g.nyaw};
+    int src = 0;
+    // the CSV is the source of truth (the reference's own cache): the side-car stands in for it only while it is at least as new -- a `.map`
+    // regenerated later (by the reference, from another cloud or other ellipsoid parameters) wins over a stale side-car
+    bool bin_fresh = bin_path != nullptr;
+    if (bin_path && csv_path) {
+        struct stat sb, sc;
+        if (stat(bin_path, &sb) == 0 && stat(csv_path, &sc) == 0 &&
+            (sb.st_mtim.tv_sec < sc.st_mtim.tv_sec || (sb.st_mtim.tv_sec == sc.st_mtim.tv_sec && sb.st_mtim.tv_nsec < sc.st_mtim.tv_nsec))) bin_fresh = false;
+    }
+    if (bin_fresh && uph_map_load_bin(bin_path, d, cells.data()) == UPH_OK) src = 2;
+    if (!src && csv_path && uph_map_load_csv(csv_path, d, cells.data(), nullptr, nullptr) == UPH_OK) src = 1;
+    if (!src) { setError(std::string("uph_map_load_cache: no readable cache (") + uph_last_error() + ")"); return UPH_ERR_INVALID; }
+    if (source) *source = src;
+    return uph_map_set_cells(m, cells.data());
+}
+
 int uph_map_get_window(uph_map* m, int32_t x0, int32_t x1, int32_t y0, int32_t y1, double* rxs2) {
     if (!m || !rxs2 || x0 < m->g.x_off || y0 < 0 || x1 > m->g.x_off + m->g.nx_hold || y1 > m->g.ny || x0 >= x1 || y0 >= y1) { setError("uph_map_get_window: bad arguments (x is a global row index inside the held rows)"); return UPH_ERR_INVALID; }
     HIPCHK(hipSetDevice(m->device));
@@ -1072,6 +1112,9 @@ Clique* getClique(const std::vector<int>& devs, const RcclApi* api, std::string&
 
 // slab rule shared with the host mirrors (uneven_planner_amd/uneven_map.py slab_bounds): per = ceil(nx / n)
 inline void slabOf(int nx, int g, int n, int& per, int& x0, int& x1) { per = (nx + n - 1) / n; x0 = std::min(g * per, nx); x1 = std::min(x0 + per, nx); }
+// the all-gather runs IN PLACE on the cell arrays (send buffer = the slab where it lies) when every slab is full; otherwise through staging of
+// n x per zero-padded rows
+inline bool slabsInPlace(int nx, int n) { return nx % n == 0; }
 
 int checkMultiMaps(uph_map* const* maps, int n, const char* who, bool need_f64) {
     if (!maps || n < 1) { setError(std::string(who) + ": bad arguments"); return UPH_ERR_INVALID; }
@@ -1134,7 +1177,7 @@ int exchangeSlabs(uph_map* const* maps, int n, const char* who) {
     Clique* q = getClique(devs, api, why);
     if (!q) { setError(std::string(who) + ": " + why); return UPH_ERR_HIP; }
     lead->multi_rccl = 1;
-    const bool inplace = nx % n == 0;
+    const bool inplace = slabsInPlace(nx, n);
     const size_t slab_bytes = (size_t)per * row;
     const ncclDataType_t dt = lead->d_cells32 ? ncclFloat : ncclDouble;
     const size_t count = slab_bytes / (lead->d_cells32 ? sizeof(float) : sizeof(double));
@@ -1218,6 +1261,16 @@ int multiBuild(uph_map* const* maps, int n, const char* who, Fit fit) {
 }
 }  // namespace
 extern "C" {
+
+// the host-side decisions of the *_multi builds, without a device: which x-slab each of n_gpus devices fits and how the slabs are exchanged
+int uph_multi_slab_plan(int32_t nx, int32_t n_gpus, int32_t* x0, int32_t* x1, int32_t* per_out, int32_t* in_place) {
+    if (nx < 1 || n_gpus < 1 || !x0 || !x1) { setError("uph_multi_slab_plan: bad arguments"); return UPH_ERR_INVALID; }
+    int per = 0;
+    for (int g = 0; g < n_gpus; g++) { int a, b; slabOf(nx, g, n_gpus, per, a, b); x0[g] = a; x1[g] = b; }
+    if (per_out) *per_out = per;
+    if (in_place) *in_place = n_gpus > 1 && slabsInPlace(nx, n_gpus) ? 1 : 0;
+    return UPH_OK;
+}
 
 int uph_map_build_multi(uph_map* const* maps, int32_t n_gpus, const float* xyz, int64_t n) {
     DeviceRestore keep;

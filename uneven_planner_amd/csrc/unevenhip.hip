@@ -1318,6 +1318,36 @@ int uph_optimize_batch(uph_ctx* c, int32_t B, const uph_problem* probs, uph_resu
     return uph_batch_download(c, results);
 }
 
+// The split of a batch over n contexts: problems in descending predicted cost, dealt round-robin (every device gets the same mix of long and
+// short solves); inside a share the caller's order (the upload sorts by cost itself).  Pure host arithmetic: uph_multi_batch_plan exposes it
+// so that the decisions of an 8-GPU run can be checked without 8 GPUs.
+static std::vector<std::vector<int>> dealShares(int n_gpus, int B, const uph_problem* probs) {
+    std::vector<int> idx(B);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::vector<double> cost(B);
+    for (int b = 0; b < B; b++) {
+        const uph_problem& q = probs[b];
+        const bool readable = q.n_inner_xy >= 0 && q.n_inner_yaw >= 0 && (q.n_inner_yaw == 0 || q.inner_yaw);
+        cost[b] = readable ? predictedCost(q) : 0.0;      // (an invalid problem is rejected by its context's upload; it needs no balancing)
+    }
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b2) { return cost[a] > cost[b2]; });
+    std::vector<std::vector<int>> share(n_gpus);
+    for (int k = 0; k < B; k++) share[k % n_gpus].push_back(idx[k]);
+    for (auto& sh : share) std::sort(sh.begin(), sh.end());
+    return share;
+}
+
+int uph_multi_batch_plan(int32_t n_gpus, int32_t B, const uph_problem* probs, int32_t* share_of, double* predicted_cost) {
+    if (n_gpus < 1 || B <= 0 || !probs || !share_of) { setError("uph_multi_batch_plan: bad arguments"); return UPH_ERR_INVALID; }
+    const std::vector<std::vector<int>> share = dealShares(n_gpus, B, probs);
+    for (int g = 0; g < n_gpus; g++) for (int b : share[g]) share_of[b] = g;
+    if (predicted_cost) for (int b = 0; b < B; b++) {
+        const uph_problem& q = probs[b];
+        predicted_cost[b] = (q.n_inner_xy >= 0 && q.n_inner_yaw >= 0 && (q.n_inner_yaw == 0 || q.inner_yaw)) ? predictedCost(q) : 0.0;
+    }
+    return UPH_OK;
+}
+
 // ---- one batch over several GPUs of this process (independent trajectories, replicated grid, no collective) --------
 // Problems are dealt to the contexts in descending predicted cost, round-robin, so every device gets the same mix of long and short
 // solves; one host thread per device runs upload -> solve -> download on its share (the calls block, the devices run concurrently).
@@ -1332,20 +1362,7 @@ int uph_optimize_batch_multi(uph_ctx* const* ctxs, int32_t n_gpus, int32_t B, co
     int dev_on_entry = -1;
     (void)hipGetDevice(&dev_on_entry);                 // the worker threads set their own device; the caller's current device is left as it was
     struct DevRestore { int d; ~DevRestore() { if (d >= 0) (void)hipSetDevice(d); } } dev_restore{dev_on_entry};
-    std::vector<int> idx(B);
-    std::iota(idx.begin(), idx.end(), 0);
-    {
-        std::vector<double> cost(B);
-        for (int b = 0; b < B; b++) {
-            const uph_problem& q = probs[b];
-            const bool readable = q.n_inner_xy >= 0 && q.n_inner_yaw >= 0 && (q.n_inner_yaw == 0 || q.inner_yaw);
-            cost[b] = readable ? predictedCost(q) : 0.0;      // (an invalid problem is rejected by its context's upload; it needs no balancing)
-        }
-        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b2) { return cost[a] > cost[b2]; });
-    }
-    std::vector<std::vector<int>> share(n_gpus);
-    for (int k = 0; k < B; k++) share[k % n_gpus].push_back(idx[k]);
-    for (auto& sh : share) std::sort(sh.begin(), sh.end());      // inside a share: the caller's order (the upload sorts by cost itself)
+    const std::vector<std::vector<int>> share = dealShares(n_gpus, B, probs);
     std::vector<int> rc(n_gpus, UPH_OK);
     std::vector<std::string> err(n_gpus);
     std::vector<std::vector<uph_problem>> pg(n_gpus);

@@ -171,19 +171,16 @@ class UnevenMap:
     def init(self, pcd_file=None, map_file=None, xyz=None):
         """UnevenMap::init (uneven_map.cpp:73-268), data part: read the cloud, then constructMapInput() (the `.map`
         text cache) if it exists, else constructMap() on the GPU and write the cache."""
-        # the `.map` CSV is the source of truth (the reference's cache, uneven_map.cpp:270-315); the binary side-car only stands in for it while
-        # it is at least as new -- a `.map` regenerated later (by the reference, from another cloud or other ellipsoid parameters) wins
-        if map_file and os.path.exists(map_file) and os.path.exists(map_file + ".bin") and os.path.getmtime(map_file + ".bin") >= os.path.getmtime(map_file):
-            self.constructMapInputBinary(map_file + ".bin")      # bit-exact side-car of the 6-digit CSV (written below)
-        elif map_file and os.path.exists(map_file):
-            self.constructMapInput(map_file)           # (cells carry the CSV's six significant digits; no side-car is derived from them)
-        else:
-            if xyz is None:
-                xyz = read_pcd(pcd_file)
-            self.build(xyz)
-            if map_file:
-                self.write_map_file(map_file)
-                self.write_map_binary(map_file + ".bin")
+        # uph_map_load_cache = constructMapInput: the `.map` CSV is the source of truth (the reference's cache, uneven_map.cpp:270-315); the binary
+        # side-car only stands in for it while it is at least as new -- a `.map` regenerated later wins.  No cache: build, then write both
+        # (the "to txt" block at the end of constructMap, :400-412, + the bit-exact side-car).  All of it in the C-ABI (csrc/map_io_host.cpp).
+        if map_file and self.load_cache(map_file):
+            return self
+        if xyz is None:
+            xyz = read_pcd(pcd_file)
+        self.build(xyz)
+        if map_file:
+            self.save_cache(map_file)
         return self
 
     def build(self, xyz, x0=0, x1=None, download=True):
@@ -345,7 +342,22 @@ class UnevenMap:
         _lib.check(maps[0].L.uph_map_multi_stats(maps[0].h, *[C.byref(x) for x in v], C.byref(r)), "uph_map_multi_stats")
         return dict(fit_ms=v[0].value, exchange_ms=v[1].value, commit_ms=v[2].value, exchange_device_ms=v[3].value, via_rccl=bool(r.value))
 
-    # ---- `.map` text cache (uneven_map.cpp:270-315, 400-412) ------------------------------------------------------
+    # ---- `.map` cache through the C-ABI (uph_map_load_cache / uph_map_save_cache) ----------------------------------
+    def load_cache(self, map_file):
+        """constructMapInput: False when neither `map_file` nor `map_file.bin` can be read; self.cache_source = "bin" / "csv" otherwise"""
+        src = C.c_int32(0)
+        rc = self.L.uph_map_load_cache(self.h, map_file.encode(), (map_file + ".bin").encode(), C.byref(src))
+        if rc != 0:
+            return False
+        self.cache_source = {1: "csv", 2: "bin"}[src.value]
+        self.download()
+        self.map_ready = True
+        return True
+
+    def save_cache(self, map_file, sidecar=True):
+        _lib.check(self.L.uph_map_save_cache(self.h, map_file.encode(), (map_file + ".bin").encode() if sidecar else None), "uph_map_save_cache")
+
+    # ---- `.map` text cache, host-mirror form (uneven_map.cpp:270-315, 400-412) ---------------------------------------
     def write_map_file(self, path):
         """CSV `x,y,yaw,z,sigma,zbx,zby`, default ostream precision (6 significant digits) like the reference."""
         self.host.write_map_file(path)
