@@ -576,8 +576,10 @@ def window_oracle(umap, prob, margin=8.0):
     """Checker for grids too large to copy to the host (BASELINE.json configs[4], 1e9 cells): the cells of the xy window around one
     problem, downloaded from the device map `umap` (UnevenMap.get_window), as an OracleGrid of that window's size, and the problem
     translated into the window's frame.  The translation is a whole number of cells, so it is exact in floating point and the
-    window grid holds the same cell values at the same relative positions; only the (x - origin) roundings inside the lookups
-    differ (~1e-13 relative).  Returns (grid, shifted problem, (sx, sy))."""
+    window grid holds the same cell values at the same relative positions.  The product solves such problems in a local frame of the
+    same kind (uph_common.hpp TrajFrame: the cell corner nearest the middle of the initial path's bounding box -- the window's centre
+    here), so both form the lookups' differences, and the ||x||-normalised stop test of lbfgs.hpp:599-606, on numbers of the path's
+    own size.  Returns (grid, shifted problem, (sx, sy))."""
     res = float(umap.xy_resolution)
     nx, ny = int(umap.voxel_num[0]), int(umap.voxel_num[1])
     pts = np.concatenate([np.asarray(prob["init_xy"])[:, :1], np.asarray(prob["end_xy"])[:, :1], np.asarray(prob["inner_xy"]).reshape(2, -1)], axis=1)

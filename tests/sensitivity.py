@@ -11,7 +11,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def solve_with_fma_oracle(cells, probs, params=None, grid_kw=None):
+def solve_many(make_alm, probs, threads=1):
+    """one oracle solve per problem; threads > 1: one trajectory per host thread (the oracle's C entry points release the GIL; every solve has
+    its own OracleALM, the grid is only read)"""
+    if threads <= 1:
+        return [make_alm().optimize(p) for p in probs]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(lambda p: make_alm().optimize(p), probs))
+
+
+def solve_with_fma_oracle(cells, probs, params=None, grid_kw=None, threads=1):
     from oracle import oracle_py as O
     so = "/tmp/liboracle_fma_%d.so" % os.getpid()
     subprocess.check_call(["g++", "-O3", "-march=native", "-ffp-contract=fast", "-std=c++17", "-fPIC", "-shared", "-o", so,
@@ -23,7 +33,7 @@ def solve_with_fma_oracle(cells, probs, params=None, grid_kw=None):
     try:
         g = O.OracleGrid(**(grid_kw or {}))
         g.set_cells(cells)
-        out = [O.OracleALM(g, params).optimize(p) for p in probs]
+        out = solve_many(lambda: O.OracleALM(g, params), probs, threads)
     finally:
         O.os.path.join = real
         O._LIB = saved

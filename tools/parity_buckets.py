@@ -42,8 +42,9 @@ def main():
     og.set_cells(m.map_buffer)
     report = {}
     for tag, prm in PARAM_SETS:
-        ref = [O.OracleALM(og, prm).optimize(p) for p in probs]
-        fma = sensitivity.solve_with_fma_oracle(m.map_buffer, probs, prm)
+        T = int(os.environ.get("UPH_PB_THREADS", "1"))          # host threads for the two CPU legs (N >= 4096: minutes on one thread)
+        ref = sensitivity.solve_many(lambda: O.OracleALM(og, prm), probs, T)
+        fma = sensitivity.solve_with_fma_oracle(m.map_buffer, probs, prm, threads=T)
         opt = U.ALMTrajOpt(m, prm)
         opt.set_lanes(128)
         opt.set_rho(1.0)

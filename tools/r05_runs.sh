@@ -39,4 +39,35 @@ print(json.dumps(r.get("parity_floor"), indent=None)[:1500])
 PY
 bash tools/pmc_phases.sh r05a lds 2>&1 | tee $OUT/pmc_phases_lds.txt
 ;;
+2)
+# the two tests call 1 failed (cache write order, cost tolerance of capped solves), the new forest / mountain tier, local frames through per-trajectory
+# grid descriptors: hill bit-identity again + A/B against round 4 and against the build without in-kernel timers, the drift statistics at N = 4096
+OUT=gpurun_out/r05b; mkdir -p $OUT
+python tools/cmp_variant.py $OUT/x_default.npy 2>&1 | tail -1
+UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_r04.so python tools/cmp_variant.py $OUT/x_r04.npy 2>&1 | tail -1
+UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_nocyc.so python tools/cmp_variant.py $OUT/x_nocyc.npy 2>&1 | tail -1
+python -c "
+import numpy as np
+a, b, c = np.load('$OUT/x_default.npy'), np.load('$OUT/x_r04.npy'), np.load('$OUT/x_nocyc.npy')
+print('hill, 64 solves: this build vs round 4 library bit-identical', np.array_equal(a, b), '; build without in-kernel timers bit-identical', np.array_equal(a, c))" | tee $OUT/bit_identity.txt
+timeout 900 python -m pytest tests/test_gpu_km2.py tests/test_gpu_map.py tests/test_gpu_forest.py tests/test_gpu_kino.py tests/test_gpu_adapter.py tests/test_gpu_tiles.py -m gpu -q -s > $OUT/gpu_tests.txt 2>&1; echo "rc $?" >> $OUT/gpu_tests.txt
+grep -E "far-from|within 1e-4|forest|passed|failed|rc |Error|assert" $OUT/gpu_tests.txt | cut -c1-400 | tail -40
+for v in default r04 nocyc default r04 nocyc; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu --no-extras > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  python - $OUT/bench_$v.json $v <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+    print('%-10s value %.0f traj/s  launch %.1f ms  frac %.3f  converged %.3f' % (sys.argv[2], r['value'], r['roofline']['avg_launch_ms'], r['roofline']['frac'], r['converged_frac']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e, open(sys.argv[1].replace('.json', '.err')).read()[-400:])
+PY
+done 2>&1 | tee $OUT/ab.txt
+unset UNEVENHIP_LIB
+UPH_PB_ONLY_YAML=1 UPH_PB_THREADS=96 timeout 900 python tools/parity_buckets.py 4096 $OUT/parity_buckets_hill_4096.json hill > $OUT/parity_buckets_hill_4096.txt 2>&1
+tail -12 $OUT/parity_buckets_hill_4096.txt | cut -c1-700
+UPH_PB_THREADS=96 timeout 900 python tools/parity_buckets.py 4096 $OUT/parity_buckets_desert_4096.json desert > $OUT/parity_buckets_desert_4096.txt 2>&1
+tail -12 $OUT/parity_buckets_desert_4096.txt | cut -c1-700
+;;
 esac

@@ -742,8 +742,8 @@ int uph_map_save_cache(uph_map* m, const char* csv_path, const char* bin_path) {
     int r = uph_map_get_cells(m, cells.data(), nullptr, nullptr, nullptr);
     if (r != UPH_OK) return r;
     const int32_t d[3] = {m->g.nx, m->g.ny, m->g.nyaw};
-    if (bin_path && (r = uph_map_save_bin(bin_path, cells.data(), d)) != UPH_OK) return r;
     if (csv_path && (r = uph_map_save_csv(csv_path, cells.data(), d)) != UPH_OK) return r;
+    if (bin_path && (r = uph_map_save_bin(bin_path, cells.data(), d)) != UPH_OK) return r;      // (after the CSV: uph_map_load_cache trusts a side-car that is not older than it)
     return UPH_OK;
 }
 // load = constructMapInput: the side-car when bin_path names a readable one for this grid (bit-exact), else the CSV (six digits); the cells

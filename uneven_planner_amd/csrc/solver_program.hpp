@@ -275,16 +275,10 @@ struct Solver {
     }
 
     // ------------------------------------------------------------------ per-sample kinematics + terrain
-    // the grid descriptor as this trajectory's lookups see it: the map's, or -- far from the map's origin -- its local frame (TrajFrame)
-    static UPH_HD void applyFrame(GridDev& g, const TrajFrame& f) {
-        g.origin[0] = f.fo[0]; g.origin[1] = f.fo[1];
-        g.lo[0] = f.lo[0]; g.lo[1] = f.lo[1]; g.hi[0] = f.hi[0]; g.hi[1] = f.hi[1];
-        g.ix_off = f.ioff[0]; g.iy_off = f.ioff[1];
-    }
+    // the grid descriptor as this trajectory's lookups see it: the map's, or -- far from the map's origin -- its local frame's (TrajFrame)
     UPH_HD GridDev framedGrid() const {
-        GridDev g = grid;
-        if (bd.frames != nullptr) applyFrame(g, bd.frames[bidx]);
-        return g;
+        if (bd.grid_mem != nullptr && bd.grid_per_traj != 0) return bd.grid_mem[bidx];
+        return grid;
     }
 
     template <class R>
@@ -309,7 +303,8 @@ struct Solver {
         // the grid descriptor through an opaque constant-address-space pointer: scalar loads issued here, nothing for the compiler to
         // keep live (and spill to VGPR lanes) across the solver's loops
         typedef const __attribute__((address_space(4))) unsigned long long* gw_t;
-        gw_t T = (gw_t)(const void*)bd.grid_mem;
+        // (one descriptor shared by the batch, or -- local frames, uph_common.hpp TrajFrame -- this trajectory's own: the same loads off another base)
+        gw_t T = (gw_t)(const void*)(bd.grid_mem + (size_t)bidx * bd.grid_per_traj);
         asm volatile("" : "+s"(T));
         constexpr int NWORD = (int)(sizeof(GridDev) / 8);
         unsigned long long w[NWORD];
@@ -317,17 +312,6 @@ struct Solver {
         for (int k = 0; k < NWORD; k++) w[k] = T[k];
         GridDev gl;
         __builtin_memcpy(&gl, w, sizeof(GridDev));
-        if (bd.frames != nullptr) {                 // (wave-uniform: a kernel argument) the trajectory's local frame, through the same kind of scalar loads
-            gw_t F = (gw_t)(const void*)(bd.frames + bidx);
-            asm volatile("" : "+s"(F));
-            constexpr int FWORD = (int)(sizeof(TrajFrame) / 8);
-            unsigned long long fw[FWORD];
-#pragma unroll
-            for (int k = 0; k < FWORD; k++) fw[k] = F[k];
-            TrajFrame fr;
-            __builtin_memcpy(&fr, fw, sizeof(TrajFrame));
-            applyFrame(gl, fr);
-        }
         terrainBase<R>(gl, S_.pos[0], S_.pos[1], S_.yawn, sg, S_.zx, S_.zy, S_.gs, S_.gzx, S_.gzy);
 #else
         const GridDev gl = framedGrid();

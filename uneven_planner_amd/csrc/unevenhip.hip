@@ -189,8 +189,16 @@ struct DevWG {
     }
     __device__ __forceinline__ void sync() { bar(0); }
     __device__ __forceinline__ int size() const { return NT; }
+#ifndef UPH_CYC
+#define UPH_CYC 1      // in-kernel phase timers (uph_batch_cycles, tools/phase_breakdown.py); 0 compiles them out (every stamp reads 0)
+#endif
+#if UPH_CYC
     __device__ __forceinline__ long long clock() { return (long long)__builtin_readcyclecounter(); }
     __device__ __forceinline__ long long realtime() { return (long long)__builtin_amdgcn_s_memrealtime(); }      // constant 100 MHz
+#else
+    __device__ __forceinline__ long long clock() { return 0; }
+    __device__ __forceinline__ long long realtime() { return 0; }
+#endif
     template <class F>
     __device__ __forceinline__ void one(F f) { if (tid == 0) f(); }
 
@@ -676,7 +684,7 @@ struct uph_ctx {
     int n_rejected = 0;
     bool all_rejected = false;              // the last upload failed because EVERY problem was unsupported (not because of a misuse or a resource limit)
     std::vector<TrajFrame> frames;          // per-trajectory local frames of the uploaded batch (empty: the map's own frame, uph_common.hpp TrajFrame)
-    DevBuf d_frames;
+    std::vector<GridDev> grid_host_framed;  // ... and the per-trajectory grid descriptors made from them (source of the asynchronous copy)
     std::vector<int> origin;                // batch loaded by uph_optimize_batch_multi: the caller's index of each problem of this context's share (empty: identity)
     bool sample_f32 = false;                // fp32 sample arithmetic (uph_ctx_set_sample_precision)
     int xcd_group = 0;                      // experiment knob (uph_ctx_set_xcd_locality): > 0 = permute the launch order inside groups of that many workgroups for per-XCD L2 locality
@@ -726,7 +734,7 @@ static BatchDev makeBatchDev(uph_ctx* c) {
     bd.trace_cap = c->trace_cap_up;
     bd.order = c->d_order.as<int>();
     bd.thomas = c->d_thomas.as<double>();
-    bd.frames = c->frames.empty() ? nullptr : c->d_frames.as<TrajFrame>();
+    bd.grid_per_traj = c->frames.empty() ? 0 : 1;
     bd.grid_mem = c->d_gridmem.as<GridDev>();
     bd.params_mem = c->d_parammem.as<OptParams>();
     bd.rs_d = c->d_rsd.as<double>(); bd.rs = c->d_rs.as<double>();
@@ -760,9 +768,18 @@ static int launchSolver(uph_ctx* c, int mode, int repeat, bool async = false, hi
     if (!evb) { evb = c->ev0; eve = c->ev1; }
     HIPCHK(hipSetDevice(uphMapDevice(c->map)));
     GridDev grid = uphMapGrid(c->map);
-    if (c->d_gridmem.ensure(sizeof(GridDev))) return UPH_ERR_HIP;
     c->grid_host = grid;
-    HIPCHK(hipMemcpyAsync(c->d_gridmem.p, &c->grid_host, sizeof(GridDev), hipMemcpyHostToDevice, c->stream));
+    if (c->frames.empty()) {
+        if (c->d_gridmem.ensure(sizeof(GridDev))) return UPH_ERR_HIP;
+        HIPCHK(hipMemcpyAsync(c->d_gridmem.p, &c->grid_host, sizeof(GridDev), hipMemcpyHostToDevice, c->stream));
+    } else {
+        // local frames: one descriptor per trajectory = the map's with the frame's origin, bounds and cell-index offset (made from the map's CURRENT
+        // descriptor at every launch, like the shared one: a rebuilt map may have moved its cells)
+        if (c->d_gridmem.ensure(sizeof(GridDev) * c->frames.size())) return UPH_ERR_HIP;
+        c->grid_host_framed.assign(c->frames.size(), grid);
+        for (size_t b = 0; b < c->frames.size(); b++) applyFrame(c->grid_host_framed[b], c->frames[b]);
+        HIPCHK(hipMemcpyAsync(c->d_gridmem.p, c->grid_host_framed.data(), sizeof(GridDev) * c->frames.size(), hipMemcpyHostToDevice, c->stream));
+    }
     if (c->d_parammem.ensure(sizeof(OptParams))) return UPH_ERR_HIP;
     HIPCHK(hipMemcpyAsync(c->d_parammem.p, &c->P, sizeof(OptParams), hipMemcpyHostToDevice, c->stream));
     BatchDev bd = makeBatchDev(c);
@@ -914,7 +931,7 @@ void uph_ctx_destroy(uph_ctx* c) {
     hipSetDevice(c->device);             // not via c->map: the map may already have been destroyed by the caller
     for (void* p : c->op_allocs) hipFree(p);
     DevBuf* bufs[] = {&c->d_ops, &c->d_desc, &c->d_state, &c->d_x, &c->d_gout, &c->d_dual, &c->d_res, &c->d_scl, &c->d_cxy, &c->d_cyaw,
-                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas, &c->d_rsd, &c->d_rs, &c->d_gridmem, &c->d_parammem, &c->d_frames};
+                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas, &c->d_rsd, &c->d_rs, &c->d_gridmem, &c->d_parammem};
     for (DevBuf* b : bufs) b->release();
     HostBuf* hbufs[] = {&c->h_x, &c->h_cxy, &c->h_cyaw, &c->h_dual, &c->h_res, &c->h_scl};
     for (HostBuf* b : hbufs) b->release();
@@ -1070,7 +1087,7 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     if (c->d_desc.ensure(sizeof(TrajDesc) * B) || c->d_state.ensure(sizeof(TrajState) * B) || c->d_x.ensure(8 * on) || c->d_x0.ensure(8 * on) || c->d_gout.ensure(8 * on) ||
         c->d_dual.ensure(8 * 7 * os) || c->d_res.ensure(8 * 7 * os) || c->d_scl.ensure(8 * 7 * os) || c->d_cxy.ensure(8 * ocx) || c->d_cyaw.ensure(8 * ocy) ||
         c->d_hist.ensure(8 * oh) || c->d_report.ensure(8 * 7 * B) || c->d_order.ensure(4 * B) ||
-        c->d_trace.ensure(8 * (size_t)std::max(1, c->trace_cap) * B) || c->d_frames.ensure(sizeof(TrajFrame) * std::max<size_t>(1, c->frames.size())))
+        c->d_trace.ensure(8 * (size_t)std::max(1, c->trace_cap) * B))
         return UPH_ERR_HIP;
     // x0 = [tau | Pxy | Pyaw]  (alm_traj_opt.cpp:206-216)
     std::vector<double> x0(on);
@@ -1140,7 +1157,6 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     HIPCHK(hipMemcpy(c->d_x.p, x0.data(), 8 * on, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_x0.p, x0.data(), 8 * on, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_order.p, c->order.data(), 4 * B, hipMemcpyHostToDevice));
-    if (!c->frames.empty()) HIPCHK(hipMemcpy(c->d_frames.p, c->frames.data(), sizeof(TrajFrame) * B, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_state.p, c->state_host.data(), sizeof(TrajState) * B, hipMemcpyHostToDevice));
     // duals = 0, residuals = 0, scales = 1 (alm_traj_opt.cpp:193-203) so that the test hooks see a defined state
     // (all on the context's own stream, waited for with a STREAM synchronise: a device-wide one would block this host thread on every other

@@ -113,8 +113,10 @@ struct MincoOp {
 // rounding where the 10 m maps of the reference carry 1e-15 -- the seed the optimiser then amplifies.  On such a grid every
 // trajectory is solved in a frame translated by a WHOLE number of cells to a cell corner next to its own path (shift = origin + ioff * resolution:
 // the translation of every way-point and end state is exact, the cells are the same cells): the lookups run with the frame's origin (0) and bounds
-// and add ioff to the cell index.  Way-points and the t^0 coefficients return in map coordinates.  Grids within +-FRAME_EXTENT of the origin --
-// every map of the reference -- keep the map's own frame (BatchDev::frames == nullptr: the arithmetic and the code path of the plain lookup).
+// and add ioff to the cell index -- through a grid descriptor of the trajectory's own (BatchDev::grid_mem holds one per trajectory then, patched on
+// the host by applyFrame; the kernel reads "its" descriptor exactly as it reads the shared one).  Way-points and the t^0 coefficients return in map
+// coordinates.  Grids within +-FRAME_EXTENT of the origin -- every map of the reference -- keep the map's own frame: one shared descriptor
+// (BatchDev::grid_per_traj == 0), the arithmetic and the instructions of the plain lookup.
 constexpr double FRAME_EXTENT = 32.0;
 struct TrajFrame {
     double fo[2];               // frame origin that replaces GridDev::origin[0..1] in the lookup (0: the frame's corner IS a cell corner)
@@ -122,6 +124,11 @@ struct TrajFrame {
     double shift[2];            // map coordinate of the frame's corner: frame = map - shift
     int ioff[2];                // cell index of the frame's corner
 };
+inline void applyFrame(GridDev& g, const TrajFrame& f) {
+    g.origin[0] = f.fo[0]; g.origin[1] = f.fo[1];
+    g.lo[0] = f.lo[0]; g.lo[1] = f.lo[1]; g.hi[0] = f.hi[0]; g.hi[1] = f.hi[1];
+    g.ix_off = f.ioff[0]; g.iy_off = f.ioff[1];
+}
 
 // One trajectory of a batch: sizes and offsets into the packed batch arrays
 struct TrajDesc {
@@ -165,7 +172,7 @@ struct BatchDev {
     const int* order;   // optional launch order: workgroup w solves trajectory order[w] (longest first)
     const OptParams* params_mem;   // the optimiser parameters in device memory, for the same reason as grid_mem
     const GridDev* grid_mem;   // the grid descriptor in device memory (same content as the kernel argument): the penalty kernel re-reads it with scalar loads per sample chunk instead of holding ~50 SGPRs across the whole solve
-    const TrajFrame* frames;   // per-trajectory local frames (nullptr: every trajectory of the batch lives in the map's own frame)
+    int grid_per_traj;      // 0: grid_mem is ONE descriptor shared by the batch (the map's own frame); 1: one descriptor per trajectory, index = trajectory (local frames)
     const double* thomas;   // block-LU factors of the MINCO knot system, THOMAS_DOUBLES (minco_op_host.hpp); shared by every trajectory, copied to LDS per workgroup
 };
 
