@@ -393,7 +393,9 @@ int uph_batch_stats(uph_ctx* c, double* kernel_ms, int64_t* evals, int64_t* samp
 int uph_batch_prepare_ms(uph_ctx* c, double* ms);
 
 /* diagnostic: shader-clock cycles per phase of the last uph_batch_solve, out[B][16]:
- * 0 MINCO generate, 1 constraint samples, 2 per-piece scatter, 3 adjoint, 4 L-BFGS two-loop, 5 initScaling, 6 whole solve */
+ * 0 MINCO generate, 1 constraint samples, 2 per-piece scatter, 3 adjoint, 4 L-BFGS two-loop, 5 initScaling, 6 whole solve.
+ * All zero in the shipped library: the in-kernel timers are compiled out (they cost 1.7 % of a solve launch); build with -DUPH_CYC=1 for them
+ * (tools/build_variants.sh cyc="-DUPH_CYC=1"). */
 int uph_batch_cycles(uph_ctx* c, long long* out);
 
 /* test / bench hooks on the uploaded batch (state = duals, scales, rho as currently resident):
@@ -402,7 +404,7 @@ int uph_batch_cycles(uph_ctx* c, long long* out);
 int uph_eval_batch(uph_ctx* c, const double* x_packed, double* f, double* grad_packed, int32_t repeat);
 int uph_init_scaling_batch(uph_ctx* c);
 /* diagnostic: measures the workgroup primitives (barrier, reductions, dependent global load, ...) on the uploaded batch;
- * per-trajectory results via uph_batch_cycles */
+ * per-trajectory results via uph_batch_cycles (a -DUPH_CYC=1 build) */
 int uph_microbench_batch(uph_ctx* c, int32_t reps);
 /* overwrite resident duals / scales (packed in the reference's order; any pointer may be NULL) */
 int uph_batch_set_state(uph_ctx* c, const double* lambda, const double* mu, const double* scale_cx, const double* scale_fx, const double* rho);

@@ -76,8 +76,8 @@ def test_forest_cloud_filter_merges_voxels_identically_on_device_and_host(forest
 
 
 @pytest.mark.parametrize("scene", ["forest", "mountain"])
-def test_map_slabs_match_the_oracle(scene, forest, mountain, oracle):
-    xyz, m, mp, _ = forest if scene == "forest" else mountain
+def test_map_slabs_match_the_oracle(scene, request, oracle):
+    xyz, m, mp, _ = request.getfixturevalue(scene)
     g = oracle.OracleGrid()
     b = oracle.OracleMapBuilder(xyz=xyz)
     nx, ny, nyaw = g.dims
@@ -96,10 +96,10 @@ def test_map_slabs_match_the_oracle(scene, forest, mountain, oracle):
 
 
 @pytest.mark.parametrize("scene", ["forest", "mountain"])
-def test_cells_match_the_independent_numpy_fit(scene, forest, mountain):
+def test_cells_match_the_independent_numpy_fit(scene, request):
     """device plane fits against the numpy / eigh restatement of constructMap (brute-force float searches over the whole cloud): every cell whose fits
     hold at least four points (below that the plane is ambiguous and the solvers may differ) to 1e-9"""
-    _, m, _, _ = forest if scene == "forest" else mountain
+    _, m, _, _ = request.getfixturevalue(scene)
     z = np.load(os.path.join(G, "mapcells_%s_golden.npz" % scene))
     nx, ny, nyaw = (int(v) for v in m.voxel_num)
     cells = m.map_buffer.reshape(nx, ny, nyaw, 4)

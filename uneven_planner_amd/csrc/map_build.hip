@@ -499,15 +499,38 @@ __global__ void uph_bstart_kernel(const int* __restrict__ skey, int n, int nb, i
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (skey[mid] < b) lo = mid + 1; else hi = mid; }
     bstart[b] = lo;
 }
-// largest point count of any (2 hw + 1)^2 bucket window: the LDS capacity of the plane-fit kernel's staging area
-__global__ void uph_cap_kernel(const int* __restrict__ bstart, int bnx, int bny, int hw, int* __restrict__ cap) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= bnx * bny) return;
-    const int ix = b / bny, iy = b % bny;
-    const int xa = max(0, ix - hw), xb = min(bnx, ix + hw + 1), ya = max(0, iy - hw), yb = min(bny, iy + hw + 1);
-    int cnt = 0;
-    for (int r = xa; r < xb; r++) cnt += bstart[r * bny + yb] - bstart[r * bny + ya];
-    atomicMax(cap, cnt);
+// LDS capacity of the plane-fit kernel's staging area = the largest point count of any disc it stages: one wave per (x, y) column of the slab counts the
+// points within the staging radius of its cell centre with the kernel's own predicate (same buckets, same float expression).  (Until round 5 the bound
+// was the largest count of a 9 x 9 window of 0.16 m buckets -- several times the disc of 0.32 m radius: on the reference's forest cloud, where trunks and
+// canopy stack thousands of points over one column, that bound passed the LDS limit although the largest disc holds 4 500 points = 72 KB.)
+__global__ __launch_bounds__(64) void uph_disc_cap_kernel(GridDev g, CloudDev cd, int x0, int x1, double ell_x, double ell_y, double ell_z, int* __restrict__ cap) {
+    const int col = blockIdx.x;
+    const int x = x0 + col / g.ny, y = col % g.ny;
+    if (x >= x1) return;
+    const int lane = threadIdx.x;
+    const double ccx = (x + 0.5) * g.xy_res + g.origin[0];
+    const double ccy = (y + 0.5) * g.xy_res + g.origin[1];
+    const double box_r = fmax(fmax(ell_x, ell_y), ell_z);
+    const float Rst = (float)(0.12 + box_r) + 1.0e-3f;               // (the expressions of uph_map_build_kernel, literally)
+    const float fcx = (float)ccx, fcy = (float)ccy;
+    const int bxa = max(0, (int)floorf((fcx - Rst - cd.bx0) / cd.bsize)), bxb = min(cd.bnx - 1, (int)floorf((fcx + Rst - cd.bx0) / cd.bsize));
+    const int bya = max(0, (int)floorf((fcy - Rst - cd.by0) / cd.bsize)), byb = min(cd.bny - 1, (int)floorf((fcy + Rst - cd.by0) / cd.bsize));
+    int count = 0;
+    for (int bx = bxa; bx <= bxb; bx++) {
+        if (bya > byb) break;
+        const int t0 = cd.bstart[bx * cd.bny + bya], t1 = cd.bstart[bx * cd.bny + byb + 1];
+        for (int base = t0; base < t1; base += 64) {
+            const int t = base + lane;
+            bool keep = false;
+            if (t < t1) {
+                const float4 p = cd.pts[t];
+                const float dx = p.x - fcx, dy = p.y - fcy;
+                keep = (dx * dx + dy * dy) <= Rst * Rst;
+            }
+            count += __popcll(__ballot(keep));
+        }
+    }
+    if (lane == 0) atomicMax(cap, count);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1003,25 +1026,23 @@ static int buildSlab(uph_map* m, const float* xyz, int64_t n, int32_t x0, int32_
     hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_key, d_skey, d_idx, d_sidx, np, 0, key_bits, 0);      // stable: filtered-cloud order inside a bucket
     hipLaunchKernelGGL(uph_pack_pts_kernel, dim3(nbp), dim3(256), 0, 0, d_sidx, np, fx, fy, fz, d_pts);
     hipLaunchKernelGGL(uph_bstart_kernel, dim3((unsigned)((nbuck + 1 + 255) / 256)), dim3(256), 0, 0, d_skey, np, (int)nbuck, d_bstart);
-    // LDS capacity: the largest point count of any (2 hw + 1)^2 bucket window, hw from the staging radius the kernel uses
-    // (0.12 probe offset + largest ellipsoid axis + margin): covers every staged disc for whatever ellipsoid the parameters give
-    const double box_r = std::max(std::max(m->mp.ellipsoid_x, m->mp.ellipsoid_y), m->mp.ellipsoid_z);
-    const int hw = (int)std::ceil((0.12 + box_r + 1.0e-3) / bsize) + 1;
+    // LDS capacity of the staging area: the largest point count of any disc the kernel stages (uph_disc_cap_kernel: the kernel's own predicate over
+    // the columns of this slab) -- exact, so a cloud fits whenever its densest disc does (9 600 points = 150 KB)
+    CloudDev cd;
+    cd.pts = d_pts; cd.bstart = d_bstart; cd.bx0 = bx0; cd.by0 = by0; cd.bsize = bsize; cd.bnx = bnx; cd.bny = bny; cd.npts = np;
+    const int ncol = (x1 - x0) * g.ny;
     int cap = 64;
     HIPCHK(hipMemcpy(d_small + 8, &cap, 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(uph_cap_kernel, dim3((unsigned)((nbuck + 255) / 256)), dim3(256), 0, 0, d_bstart, bnx, bny, hw, (int*)(d_small + 8));
+    hipLaunchKernelGGL(uph_disc_cap_kernel, dim3(ncol), dim3(64), 0, 0, g, cd, (int)x0, (int)x1, m->mp.ellipsoid_x, m->mp.ellipsoid_y, m->mp.ellipsoid_z, (int*)(d_small + 8));
     int ovf0 = 0;
     HIPCHK(hipMemcpy(d_small + 9, &ovf0, 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(&cap, d_small + 8, 4, hipMemcpyDeviceToHost));
     HIPCHK(hipGetLastError());
     m->stage_ms[2] = lap();
     const size_t lds_bytes = (size_t)cap * sizeof(float4);
-    if (lds_bytes > 150 * 1024) { setError("uph_map_build: cloud too dense for the LDS staging window"); return UPH_ERR_LIMIT; }
-    CloudDev cd;
-    cd.pts = d_pts; cd.bstart = d_bstart; cd.bx0 = bx0; cd.by0 = by0; cd.bsize = bsize; cd.bnx = bnx; cd.bny = bny; cd.npts = np;
+    if (lds_bytes > 150 * 1024) { setError("uph_map_build: cloud too dense for the LDS staging window (" + std::to_string(cap) + " points within the staging radius of one cell centre; 9600 fit)"); return UPH_ERR_LIMIT; }
     HIPCHK(hipFuncSetAttribute((const void*)uph_map_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     if (!m->bev0) { HIPCHK(hipEventCreate(&m->bev0)); HIPCHK(hipEventCreate(&m->bev1)); }
-    const int ncol = (x1 - x0) * g.ny;
     HIPCHK(hipEventRecord(m->bev0, 0));
     hipLaunchKernelGGL(uph_map_build_kernel, dim3(ncol), dim3(64), lds_bytes, 0, g, cd, m->d_cells, (int)x0, (int)x1, (int)m->mp.iter_num, m->mp.ellipsoid_x,
                        m->mp.ellipsoid_y, m->mp.ellipsoid_z, cap, (int*)(d_small + 9));

@@ -151,10 +151,10 @@ struct DevWG {
 #define UPH_MFMA_SCATTER 1
 #endif
     static constexpr bool MFMA_SCATTER = UPH_MFMA_SCATTER != 0;
-    __device__ __forceinline__ void scatterXY17(const double* rec, const double* wtab, double* Gxy, int i0_, int P_, int s0_, int cnt_) {
+    __device__ __forceinline__ void scatterXY17(const double* rec, const double* wtab, double* Gxy, int sxy_, int i0_, int P_, int s0_, int cnt_) {
         typedef double d4_t __attribute__((ext_vector_type(4)));
         constexpr int K1 = 17, NQ = 3 * K1, CHP = NT + 1;
-        const int P = uni(P_), s0 = uni(s0_), cnt = uni(cnt_), i0 = uni(i0_);
+        const int P = uni(P_), s0 = uni(s0_), cnt = uni(cnt_), i0 = uni(i0_), sxy = uni(sxy_);
         const int ntile = (2 * P + 15) >> 4;
         const int ln = flane();
         const int c = ln & 15, kk = (ln >> 4) & 3;
@@ -181,16 +181,20 @@ struct DevWG {
                 else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
             }
             if (pi < P) {
-                double* gp = Gxy + 12 * (i0 + pi) + dd;
-                gp[2 * kk] += acc0[0] + acc1[0];                         // row kk
-                if (kk < 2) gp[2 * (4 + kk)] += acc0[1] + acc1[1];       // rows 4, 5
+                double* gp = Gxy + 2 * (i0 + pi) + dd;                   // K-major G: row k of (piece, dim) at k * sxy (the 16 columns of a tile are 16 consecutive doubles)
+                gp[kk * sxy] += acc0[0] + acc1[0];                       // row kk
+                if (kk < 2) gp[(4 + kk) * sxy] += acc0[1] + acc1[1];     // rows 4, 5
             }
         }
     }
     __device__ __forceinline__ void sync() { bar(0); }
     __device__ __forceinline__ int size() const { return NT; }
+// In-kernel phase timers (uph_batch_cycles, uph_microbench_batch, tools/phase_breakdown.py): ~25 s_memtime stamps per objective evaluation, each followed
+// by a wait for the scalar-memory return, and sixteen 64-bit accumulators held (and spilled) across the solve.  The shipped library compiles them out
+// -- every stamp reads 0, the accumulation folds away: -1.7 % per solve launch, results bit for bit the same (profiles/r05b_timers_ab.txt); the
+// diagnostic build is `tools/build_variants.sh cyc="-DUPH_CYC=1"`, selected with UNEVENHIP_LIB.
 #ifndef UPH_CYC
-#define UPH_CYC 1      // in-kernel phase timers (uph_batch_cycles, tools/phase_breakdown.py); 0 compiles them out (every stamp reads 0)
+#define UPH_CYC 0
 #endif
 #if UPH_CYC
     __device__ __forceinline__ long long clock() { return (long long)__builtin_readcyclecounter(); }
