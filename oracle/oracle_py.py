@@ -593,7 +593,9 @@ def window_oracle(umap, prob, margin=8.0):
     x0, y0 = min(max(cx - n // 2, 0), nx - n), min(max(cy - n // 2, 0), ny - n)      # slide the window back inside the map near its border
     cx, cy = x0 + n // 2, y0 + n // 2
     cells = umap.get_window(x0, x0 + n, y0, y0 + n)
-    g = OracleGrid(size_x=n * res, size_y=n * res, xy_res=res, yaw_res=float(umap.yaw_resolution), gravity=float(umap.params["gravity"]))
+    kw = dict(size_x=n * res, size_y=n * res, xy_res=res, yaw_res=float(umap.yaw_resolution), gravity=float(umap.params["gravity"]))
+    g = OracleGrid(**kw)
+    g.kw, g.window_cells = kw, cells.reshape(-1, 4)          # (what a second build of the oracle needs to make the same grid: tests/sensitivity.py fma_session)
     assert g.dims[0] == n and g.dims[1] == n and g.dims[2] == int(umap.voxel_num[2]), (g.dims, n)
     g.set_cells(cells.reshape(-1, 4))
     sx, sy = ox + cx * res, oy + cy * res                 # window centre in map coordinates

@@ -112,7 +112,7 @@ struct HostWG {
         for (int j = 1; j <= len; j++) {
             double P[4], M1[4], Q[4], M2[4];
             thomasFactors<ADJ>(tab, j, P, M1, Q, M2);
-            double* p = buf + (size_t)(j - 1) * ks;
+            double* p = buf + knotOff(j - 1, ks);          // (padded per lane block of the device solve, uph_common.hpp)
             double P0, P1;
             mv2(P, p[0], p[cs], P0, P1);
             submv2(P0, P1, M1, y0, y1, y0, y1);
@@ -122,7 +122,7 @@ struct HostWG {
         for (int j = len; j >= 1; j--) {
             double P[4], M1[4], Q[4], M2[4];
             thomasFactors<ADJ>(tab, j, P, M1, Q, M2);
-            double* p = buf + (size_t)(j - 1) * ks;
+            double* p = buf + knotOff(j - 1, ks);          // (padded per lane block of the device solve, uph_common.hpp)
             double q0, q1;
             mv2(Q, p[0], p[cs], q0, q1);
             submv2(q0, q1, M2, z0, z1, z0, z1);

@@ -21,6 +21,27 @@ def solve_many(make_alm, probs, threads=1):
         return list(ex.map(lambda p: make_alm().optimize(p), probs))
 
 
+class fma_session:
+    """`with fma_session() as O:` -- inside the block the module oracle.oracle_py is bound to the oracle rebuilt with -march=native -ffp-contract=fast
+    (grids and solvers created there live in that build); the plain build is restored on exit"""
+
+    def __enter__(self):
+        from oracle import oracle_py as O
+        self.O = O
+        so = "/tmp/liboracle_fma_%d.so" % os.getpid()
+        if not os.path.exists(so):
+            subprocess.check_call(["g++", "-O3", "-march=native", "-ffp-contract=fast", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "oracle", "oracle_capi.cpp")])
+        self.saved, O._LIB = O._LIB, None
+        self.real = O.os.path.join
+        O.os.path.join = lambda *a, _r=self.real: so if a[-1] == "liboracle.so" else _r(*a)
+        return O
+
+    def __exit__(self, *exc):
+        self.O.os.path.join = self.real
+        self.O._LIB = self.saved
+        return False
+
+
 def solve_with_fma_oracle(cells, probs, params=None, grid_kw=None, threads=1):
     from oracle import oracle_py as O
     so = "/tmp/liboracle_fma_%d.so" % os.getpid()

@@ -70,4 +70,61 @@ tail -12 $OUT/parity_buckets_hill_4096.txt | cut -c1-700
 UPH_PB_THREADS=96 timeout 900 python tools/parity_buckets.py 4096 $OUT/parity_buckets_desert_4096.json desert > $OUT/parity_buckets_desert_4096.txt 2>&1
 tail -12 $OUT/parity_buckets_desert_4096.txt | cut -c1-700
 ;;
+3)
+# K-major LDS layout + timers off + exact staging capacity: bit identity against round 4's library, the whole GPU tier, the branchy far-from-origin problem
+# under other lane counts, A/B of the layout alone (nocyc = old layout without timers), LDS counters of the penalty kernel
+OUT=gpurun_out/r05c; mkdir -p $OUT
+python tools/cmp_variant.py $OUT/x_default.npy 2>&1 | tail -1
+UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_r04.so python tools/cmp_variant.py $OUT/x_r04.npy 2>&1 | tail -1
+python -c "
+import numpy as np
+a, b = np.load('$OUT/x_default.npy'), np.load('$OUT/x_r04.npy')
+print('hill, 64 solves: K-major layout, timers off vs round 4 library: bit-identical', np.array_equal(a, b))" | tee $OUT/bit_identity.txt
+timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -25 $OUT/gpu_tests.txt | cut -c1-400
+timeout 300 python tools/far_outlier_probe.py 2>&1 | grep lanes | tee $OUT/far_outlier_probe.txt
+for v in nocyc default nocyc default; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu --no-extras > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  python - $OUT/bench_$v.json $v <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+    print('%-10s value %.0f traj/s  launch %.1f ms  frac %.3f  converged %.3f  single traj %.2f ms' % (sys.argv[2], r['value'], r['roofline']['avg_launch_ms'], r['roofline']['frac'], r['converged_frac'], r['single_traj_ms']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e, open(sys.argv[1].replace('.json', '.err')).read()[-400:])
+PY
+done 2>&1 | tee $OUT/ab.txt
+unset UNEVENHIP_LIB
+bash tools/pmc_eval.sh r05c default lds 2>&1 | tail -12
+bash tools/pmc_eval.sh r05c nocyc lds 2>&1 | tail -12
+;;
+4)
+# knot buffers padded per lane block (K-major layout reverted: measured 0.3 % slower): bit identity, whole GPU tier, A/B against the packed buffers
+# (nocyc = packed, timers off), LDS counters of the penalty kernel
+OUT=gpurun_out/r05d; mkdir -p $OUT
+python tools/cmp_variant.py $OUT/x_default.npy 2>&1 | tail -1
+UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_r04.so python tools/cmp_variant.py $OUT/x_r04.npy 2>&1 | tail -1
+python -c "
+import numpy as np
+a, b = np.load('$OUT/x_default.npy'), np.load('$OUT/x_r04.npy')
+print('hill, 64 solves: padded knot buffers, timers off vs round 4 library: bit-identical', np.array_equal(a, b))" | tee $OUT/bit_identity.txt
+timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -12 $OUT/gpu_tests.txt | cut -c1-400
+timeout 300 python -m pytest tests/test_gpu_km2.py -q -s -k far_from_origin 2>&1 | grep -E "oracle solves|evaluation|passed|failed" | cut -c1-400 | tee $OUT/far_test.txt
+for v in nocyc default nocyc default; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu --no-extras > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  python - $OUT/bench_$v.json $v <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+    print('%-10s value %.0f traj/s  launch %.1f ms  frac %.3f  converged %.3f  single traj %.2f ms' % (sys.argv[2], r['value'], r['roofline']['avg_launch_ms'], r['roofline']['frac'], r['converged_frac'], r['single_traj_ms']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e, open(sys.argv[1].replace('.json', '.err')).read()[-400:])
+PY
+done 2>&1 | tee $OUT/ab.txt
+unset UNEVENHIP_LIB
+bash tools/pmc_eval.sh r05d default lds 2>&1 | grep SQ_
+;;
 esac

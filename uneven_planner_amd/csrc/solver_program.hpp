@@ -66,13 +66,6 @@ struct Solver {
     const BatchDev& bd;
     const TrajDesc& td;
     int Nxy, Nyaw, n, S, K, mem, CH, CHP, recd;
-    // Coefficients c and gradient blocks G in LDS are K-MAJOR: c_xy of (piece i, power k, dimension dd) at cxy[k * sxy + 2 i + dd], c_yaw of (piece m,
-    // power k) at cyaw[k * syw + m] (sxy = 2 Nxy, syw = Nyaw doubles; G alike).  Every parallel region indexes them by (piece, dimension) across its
-    // lanes: consecutive lanes then touch consecutive doubles -- conflict-free on the 64 LDS banks -- where the reference's [piece][k][dim] order
-    // (12 doubles per piece: pieces j and j + 8 of a 32-lane group on the same banks) replayed 58 % of the adjoint's LDS cycles
-    // (profiles/r05a_lds_by_phase.txt).  The (x, y) pair of one (piece, k) stays adjacent: a sample still fetches both with one 16-byte read.
-    // HBM and the C-ABI keep the reference's order (se2traj.hpp:570): storeTrajectory / report convert.
-    int sxy, syw;
     // workgroup-shared arrays (LDS)
     int* rtag;
     double *x, *xp, *g, *gp, *d, *cxy, *cyaw, *Gxy, *Gyaw, *gamxy, *gamyaw, *bt, *rec, *wtab, *ttab, *pf, *hd;
@@ -97,7 +90,7 @@ struct Solver {
         size_t recd = (size_t)REC_FIELDS * (CH + 1) + (CH + 1) / 2;       // double fields (stride CH + 1: bank spread) + the int32 yaw-piece tags
         const size_t nvec = 2 * (Nxy + 5) + (Nyaw + 5);
         // the record buffer is idle outside the sample loop: knot states of generate(), knot gradients + direct parts of adjoint()
-        const size_t knd = 4 * (size_t)(Nxy + 1) + 2 * (Nyaw + 1), adj = 4 * (size_t)(Nxy - 1) + 2 * (Nyaw - 1) + nvec;
+        const size_t knd = (size_t)knotBufDoubles(Nxy + 1, 4) + knotBufDoubles(Nyaw + 1, 2), adj = (size_t)knotBufDoubles(Nxy, 4) + knotBufDoubles(Nyaw, 2) + nvec;
         recd = recd < knd ? knd : recd;
         recd = recd < adj ? adj : recd;
         recd = recd < (size_t)mem ? (size_t)mem : recd;                  // ... and the two-loop's alphas
@@ -110,7 +103,6 @@ struct Solver {
         bidx = bi;
         Nxy = td.Nxy; Nyaw = td.Nyaw; n = td.n; S = td.S; K = P.int_K; mem = P.mem_size;
         inv_k1 = 1.0f / (float)(K + 1);
-        sxy = 2 * Nxy; syw = Nyaw;
         CH = wg.size(); CHP = CH + 1; recd = REC_FIELDS * CHP + (CH + 1) / 2;      // (ldsDoubles may have reserved more; only the size matters here)
         // field stride CH + 1 doubles: with stride CH (1 KB) the field rows of a piece start in the same LDS bank and the
         // scatter's per-(piece, field) lanes conflict
@@ -127,7 +119,7 @@ struct Solver {
         rec = q;                                             // (wtab sits right before rec: scatterChunk's unmasked batch reads may run past either one's end by a few words)
         {
             size_t rd = (size_t)recd;
-            const size_t knd = 4 * (size_t)(Nxy + 1) + 2 * (Nyaw + 1), adj = 4 * (size_t)(Nxy - 1) + 2 * (Nyaw - 1) + nvec;
+            const size_t knd = (size_t)knotBufDoubles(Nxy + 1, 4) + knotBufDoubles(Nyaw + 1, 2), adj = (size_t)knotBufDoubles(Nxy, 4) + knotBufDoubles(Nyaw, 2) + nvec;
             rd = rd < knd ? knd : rd; rd = rd < adj ? adj : rd; rd = rd < (size_t)mem ? (size_t)mem : rd;
             q += rd;
         }
@@ -199,15 +191,15 @@ struct Solver {
         Tyaw = wg.bcast(Ttot / (double)Nyaw);
         ec_iTyaw = wg.bcast(1.0 / Tyaw);
         const double Tx = Txy, Ty = Tyaw;
-        double* zxy = rec;
-        double* zyaw = rec + 4 * (Nxy + 1);
+        double* zxy = rec;                                   // knot j at knotOffJ(j, ks): padded per lane block of the solve (uph_common.hpp)
+        double* zyaw = rec + knotBufDoubles(Nxy + 1, 4);
         wg.pfor(2 * (Nxy + 1) + (Nyaw + 1), [&](int t) {
             const bool isxy = t < 2 * (Nxy + 1);
             const int j = isxy ? (t >> 1) : t - 2 * (Nxy + 1), dd = isxy ? (t & 1) : 2, N = isxy ? Nxy : Nyaw, os = isxy ? 2 : 1;
             const double T1 = isxy ? Tx : Ty;
             const double* h0 = isxy ? hd + (dd & 1) : hd + 12;       // {P, V, A} of the head at stride os; tail 6 (xy) / 3 (yaw) doubles further
             const double* h1 = isxy ? hd + 6 + (dd & 1) : hd + 15;
-            double* z = isxy ? zxy + 4 * j + (dd & 1) : zyaw + 2 * j;      // component stride os
+            double* z = isxy ? zxy + knotOffJ(j, 4) + (dd & 1) : zyaw + knotOffJ(j, 2);      // component stride os
             if (STEP && t == 0) xin[0] = tau_;
             if (j == 0) { z[0] = T1 * h0[os]; z[os] = T1 * T1 * h0[2 * os]; }
             else if (j == N) { z[0] = T1 * h1[os]; z[os] = T1 * T1 * h1[2 * os]; }
@@ -228,7 +220,7 @@ struct Solver {
             }
         });
         const long long tsub1 = wg.clock();
-        wg.thomas(ttab, false, zyaw + 2, Nyaw - 1, zxy + 4, Nxy - 1);
+        wg.thomas(ttab, false, zyaw + knotOffJ(1, 2), Nyaw - 1, zxy + knotOffJ(1, 4), Nxy - 1);
         if (sub_t) { sub_t[0] += tsub1 - tsub_start; sub_t[1] += wg.clock() - tsub1; }
     }
 
@@ -241,24 +233,26 @@ struct Solver {
         const long long t0 = wg.clock();
         const double Tx = Txy, Ty = Tyaw, itx = wg.bcast(1.0 / Tx), ity = wg.bcast(1.0 / Ty);
         const double* zxy = rec;
-        const double* zyaw = rec + 4 * (Nxy + 1);
+        const double* zyaw = rec + knotBufDoubles(Nxy + 1, 4);
         const int np = 2 * Nxy + Nyaw;
         wg.template sum<3>(np + 2, out, [&](int t, double* acc) {
             if (t >= np) { fillTimes(t - np); return; }
             double p0, p1, v0, a0, v1, a1, it_, T1;
             double *oc, *og;
-            int os;                                      // stride between the powers k of this (piece, dimension): K-major
+            int os;
             const bool isxy = t < 2 * Nxy;
             if (isxy) {
                 const int i = t >> 1, dd = t & 1;
                 p0 = knotPos(xin, i, dd); p1 = knotPos(xin, i + 1, dd);
-                v0 = zxy[4 * i + dd]; a0 = zxy[4 * i + 2 + dd]; v1 = zxy[4 * i + 4 + dd]; a1 = zxy[4 * i + 6 + dd];
-                oc = cxy + 2 * i + dd; og = Gxy + 2 * i + dd; os = sxy; it_ = itx; T1 = Tx;
+                const double *k0 = zxy + knotOffJ(i, 4) + dd, *k1 = zxy + knotOffJ(i + 1, 4) + dd;
+                v0 = k0[0]; a0 = k0[2]; v1 = k1[0]; a1 = k1[2];
+                oc = cxy + 12 * i + dd; og = Gxy + 12 * i + dd; os = 2; it_ = itx; T1 = Tx;
             } else {
                 const int m = t - 2 * Nxy;
                 p0 = knotPos(xin, m, 2); p1 = knotPos(xin, m + 1, 2);
-                v0 = zyaw[2 * m]; a0 = zyaw[2 * m + 1]; v1 = zyaw[2 * m + 2]; a1 = zyaw[2 * m + 3];
-                oc = cyaw + m; og = Gyaw + m; os = syw; it_ = ity; T1 = Ty;
+                const double *k0 = zyaw + knotOffJ(m, 2), *k1 = zyaw + knotOffJ(m + 1, 2);
+                v0 = k0[0]; a0 = k0[1]; v1 = k1[0]; a1 = k1[1];
+                oc = cyaw + 6 * m; og = Gyaw + 6 * m; os = 1; it_ = ity; T1 = Ty;
             }
             const double dl = p1 - p0;
             const double h3 = 10.0 * dl - 6.0 * v0 - 4.0 * v1 - 1.5 * a0 + 0.5 * a1;
@@ -344,13 +338,13 @@ struct Solver {
         S_.b1[0] = 0.0; S_.b1[1] = 1.0; S_.b1[2] = 2.0 * s1; S_.b1[3] = 3.0 * s2; S_.b1[4] = 4.0 * s3; S_.b1[5] = 5.0 * s4;
         S_.b2[0] = 0.0; S_.b2[1] = 0.0; S_.b2[2] = 2.0; S_.b2[3] = 6.0 * s1; S_.b2[4] = 12.0 * s2; S_.b2[5] = 20.0 * s3;
         S_.b3[0] = 0.0; S_.b3[1] = 0.0; S_.b3[2] = 0.0; S_.b3[3] = 6.0; S_.b3[4] = 24.0 * s1; S_.b3[5] = 60.0 * s2;
-        const double* c = cxy + 2 * i;
+        const double* c = cxy + 12 * i;
 #pragma unroll
         for (int dd = 0; dd < 2; dd++) {                                // :742-745
             R a = R(0.0), b = R(0.0), cc = R(0.0), e = R(0.0);
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                const R cv = c[k * sxy + dd];
+                const R cv = c[k * 2 + dd];
                 a += cv * S_.b0[k]; b += cv * S_.b1[k]; cc += cv * S_.b2[k]; e += cv * S_.b3[k];
             }
             S_.pos[dd] = a; S_.vel[dd] = b; S_.acc[dd] = cc; S_.jer[dd] = e;
@@ -366,10 +360,10 @@ struct Solver {
         S_.y0[0] = 1.0; S_.y0[1] = u1; S_.y0[2] = u2; S_.y0[3] = u3; S_.y0[4] = u4; S_.y0[5] = u5;
         S_.y1[0] = 0.0; S_.y1[1] = 1.0; S_.y1[2] = 2.0 * u1; S_.y1[3] = 3.0 * u2; S_.y1[4] = 4.0 * u3; S_.y1[5] = 5.0 * u4;
         S_.y2[0] = 0.0; S_.y2[1] = 0.0; S_.y2[2] = 2.0; S_.y2[3] = 6.0 * u1; S_.y2[4] = 12.0 * u2; S_.y2[5] = 20.0 * u3;
-        const double* cy = cyaw + yi;
+        const double* cy = cyaw + 6 * yi;
         R yaw = R(0.0), dyaw = R(0.0), d2yaw = R(0.0);                            // :762-764
 #pragma unroll
-        for (int k = 0; k < 6; k++) { const R cv = cy[k * syw]; yaw += cv * S_.y0[k]; dyaw += cv * S_.y1[k]; d2yaw += cv * S_.y2[k]; }
+        for (int k = 0; k < 6; k++) { const R cv = cy[k]; yaw += cv * S_.y0[k]; dyaw += cv * S_.y1[k]; d2yaw += cv * S_.y2[k]; }
         S_.yaw = yaw; S_.dyaw = dyaw; S_.d2yaw = d2yaw;
         const R yawn = normSO2(yaw);                               // :767-770
         sincosFast(yaw, S_.syaw, S_.cyaw);                              // one argument reduction for both
@@ -661,8 +655,8 @@ struct Solver {
                     a1 += in ? (pD[u] * e0[u] + (c1b * pC[u]) * e1[u] + (c2b * pB[u]) * e2[u]) : 0.0;
                 }
             }
-            Gxy[k0 * sxy + 2 * i + dd] += a0;
-            Gxy[k1 * sxy + 2 * i + dd] += a1;
+            Gxy[12 * i + 2 * k0 + dd] += a0;
+            Gxy[12 * i + 2 * k1 + dd] += a1;
         };
         // yaw outputs: lane tt owns (yaw piece, k-pair)
         auto yawTask = [&](int tt) {
@@ -696,8 +690,8 @@ struct Solver {
                     a1 += in ? v1[u] : 0.0;
                 }
             }
-            Gyaw[(2 * kp) * syw + m] += a0;
-            Gyaw[(2 * kp + 1) * syw + m] += a1;
+            Gyaw[6 * m + 2 * kp] += a0;
+            Gyaw[6 * m + 2 * kp + 1] += a1;
         };
         if constexpr (WG::MFMA_SCATTER) {
             // The xy half is a dense contraction with a SHARED left operand: G(6 x 2P) += B(6 x 3 K1) R(3 K1 x 2P), B = the power table with the
@@ -705,7 +699,7 @@ struct Solver {
             // masked to zero).  The device runs it on the matrix cores (DevWG::scatterXY17, v_mfma_f64_16x16x4_f64) for the reference's
             // int_K = 16 while the other wave(s) sum the yaw blocks; any other K takes the vector path below.
             if (K1 == 17) {
-                wg.scatterXY17(rec, wtab, Gxy, sxy, i0, i1 - i0 + 1, s0, cnt);
+                wg.scatterXY17(rec, wtab, Gxy, i0, i1 - i0 + 1, s0, cnt);
                 wg.pforRev(3 * (m1 - m0 + 1), yawTask);
                 return;
             }
@@ -726,9 +720,9 @@ struct Solver {
         const long long ta0 = wg.clock();
         const int nbx = Nxy + 5, nby = Nyaw + 5;
         const int nvec = 2 * nbx + nby;
-        double* gwxy = rec;                              // [Nxy-1][v,a][2]   (records are consumed by scatterChunk before adjoint runs)
-        double* gwyaw = gwxy + 4 * (Nxy - 1);            // [Nyaw-1][v,a]
-        double* gdir = gwyaw + 2 * (Nyaw - 1);           // [nvec] direct contributions, laid out like gamma
+        double* gwxy = rec;                              // [Nxy-1][v,a][2] at knotOff(q, 4)   (records are consumed by scatterChunk before adjoint runs)
+        double* gwyaw = gwxy + knotBufDoubles(Nxy, 4);   // [Nyaw-1][v,a] at knotOff(q, 2)
+        double* gdir = gwyaw + knotBufDoubles(Nyaw, 2);  // [nvec] direct contributions, laid out like gamma
         // One lane per (knot, dimension): transposed Hermite expansion of G T^-k -- every knot collects from the piece it opens and
         // the piece it closes; interior (v, a) go to the transposed knot solve, everything that is itself an entry of beta (all
         // positions, the end knots' V and A) straight to its column -- plus the opened piece's share of -sum_k k c_k / T * G_k.
@@ -736,17 +730,16 @@ struct Solver {
         wg.template sum<2>(2 * (Nxy + 1) + (Nyaw + 1), ch, [&](int t, double* acc) {
             const bool isxy = t < 2 * (Nxy + 1);
             const int j = isxy ? (t >> 1) : t - 2 * (Nxy + 1), dd = isxy ? (t & 1) : 0, N = isxy ? Nxy : Nyaw, os = isxy ? 2 : 1;
-            const double* G = isxy ? Gxy + dd : Gyaw;            // K-major: power k of piece j at [k * ks + j * ps]
+            const double* G = isxy ? Gxy + dd : Gyaw;
             const double* c = isxy ? cxy + dd : cyaw;
-            const int ks = isxy ? sxy : syw, ps = isxy ? 2 : 1;
             const double it_ = isxy ? itx : ity;
             const double i2 = it_ * it_, i3 = i2 * it_, i4 = i3 * it_, i5 = i4 * it_;
             double dp = 0.0, dv = 0.0, da = 0.0;
             if (j < N) {
-                const double* gl = G + j * ps;
-                const double* cl = c + j * ps;
-                const double r1 = gl[ks], r2 = gl[2 * ks], r3 = gl[3 * ks], r4 = gl[4 * ks], r5 = gl[5 * ks];
-                const double chain = -it_ * (cl[ks] * r1 + 2.0 * (cl[2 * ks] * r2) + 3.0 * (cl[3 * ks] * r3) + 4.0 * (cl[4 * ks] * r4) + 5.0 * (cl[5 * ks] * r5));
+                const double* gl = G + (size_t)6 * j * os;
+                const double* cl = c + (size_t)6 * j * os;
+                const double r1 = gl[os], r2 = gl[2 * os], r3 = gl[3 * os], r4 = gl[4 * os], r5 = gl[5 * os];
+                const double chain = -it_ * (cl[os] * r1 + 2.0 * (cl[2 * os] * r2) + 3.0 * (cl[3 * os] * r3) + 4.0 * (cl[4 * os] * r4) + 5.0 * (cl[5 * os] * r5));
                 acc[0] += isxy ? chain : 0.0;
                 acc[1] += isxy ? 0.0 : chain;
                 const double g0 = gl[0], g1 = r1 * it_, g2 = r2 * i2, g3 = r3 * i3, g4 = r4 * i4, g5 = r5 * i5;
@@ -755,8 +748,8 @@ struct Solver {
                 da += 0.5 * g2 - 1.5 * g3 + 1.5 * g4 - 0.5 * g5;
             }
             if (j > 0) {
-                const double* gr_ = G + (j - 1) * ps;
-                const double g3 = gr_[3 * ks] * i3, g4 = gr_[4 * ks] * i4, g5 = gr_[5 * ks] * i5;
+                const double* gr_ = G + (size_t)6 * (j - 1) * os;
+                const double g3 = gr_[3 * os] * i3, g4 = gr_[4 * os] * i4, g5 = gr_[5 * os] * i5;
                 dp += 10.0 * g3 - 15.0 * g4 + 6.0 * g5;
                 dv += -4.0 * g3 + 7.0 * g4 - 3.0 * g5;
                 da += 0.5 * g3 - g4 + 0.5 * g5;
@@ -765,8 +758,8 @@ struct Solver {
             gd[knotCol(j, N) * os] = dp;
             if (j == 0) { gd[1 * os] = dv; gd[2 * os] = da; }
             else if (j == N) { gd[(N + 3) * os] = dv; gd[(N + 4) * os] = da; }
-            else if (isxy) { gwxy[4 * (j - 1) + dd] = dv; gwxy[4 * (j - 1) + 2 + dd] = da; }
-            else { gwyaw[2 * (j - 1)] = dv; gwyaw[2 * (j - 1) + 1] = da; }
+            else if (isxy) { double* kq = gwxy + knotOff(j - 1, 4) + dd; kq[0] = dv; kq[2] = da; }
+            else { double* kq = gwyaw + knotOff(j - 1, 2); kq[0] = dv; kq[1] = da; }
         });
         const long long ta1 = wg.clock();
         // lambda = M^-T (knot gradients) by the transposed block sweeps, in place
@@ -783,8 +776,8 @@ struct Solver {
             const double T1 = isxy ? Tx : Ty;
             const double* h0 = isxy ? hd + dd : hd + 12;
             const double* h1 = isxy ? hd + 6 + dd : hd + 15;
-            auto L0 = [&](int j) { return (j >= 1 && j <= N - 1) ? lam[(j - 1) * ks] : 0.0; };
-            auto L1 = [&](int j) { return (j >= 1 && j <= N - 1) ? lam[(j - 1) * ks + cs] : 0.0; };
+            auto L0 = [&](int j) { return (j >= 1 && j <= N - 1) ? lam[knotOff(j - 1, ks)] : 0.0; };
+            auto L1 = [&](int j) { return (j >= 1 && j <= N - 1) ? lam[knotOff(j - 1, ks) + cs] : 0.0; };
             double a = gdir[t], hT = 0.0;
             if (col == 1) { a += 8.0 * L0(1) + 7.0 * L1(1); hT = a * h0[cs]; }                             // V0: (-A^T lambda_1)[0]
             else if (col == 2) { a += L0(1) + L1(1); hT = a * (2.0 * T1 * h0[2 * cs]); }                   // A0: (-A^T lambda_1)[1]
@@ -948,11 +941,11 @@ struct Solver {
                 for (int kk = 0; kk < 6; kk++) {
                     for (int t = 0; t < 2; t++) {
                         const double v = k.b0[kk] * gp_[t] + k.b1[kk] * gv_[t] + k.b2[kk] * ga_[t];
-                        chain_x += -(double)kk * cxy[kk * sxy + 2 * i + t] * itx * v;
+                        chain_x += -(double)kk * cxy[12 * i + kk * 2 + t] * itx * v;
                         gx_[kk][t] = v * sx;
                     }
                     const double vy = k.y0[kk] * gyaw + k.y1[kk] * gdyaw;
-                    chain_y += -(double)kk * cyaw[kk * syw + m] * ity * vy;
+                    chain_y += -(double)kk * cyaw[6 * m + kk] * ity * vy;
                     gy_[kk] = vy * sy;
                     sx *= itx; sy *= ity;
                 }
@@ -1217,11 +1210,7 @@ struct Solver {
     UPH_HD void storeTrajectory(TrajState& st) {
         double* oc = bd.cxy + td.off_cxy;
         double* oy = bd.cyaw + td.off_cyaw;
-        // (HBM keeps the reference's order: row 6 i + k of c_xy = t^k coefficient of piece i, se2traj.hpp:570)
-        wg.pfor(12 * Nxy + 6 * Nyaw, [&](int t) {
-            if (t < 12 * Nxy) { const int i = t / 12, r = t - 12 * i; oc[t] = cxy[(r >> 1) * sxy + 2 * i + (r & 1)]; }
-            else { const int u = t - 12 * Nxy, m = u / 6, k = u - 6 * m; oy[u] = cyaw[k * syw + m]; }
-        });
+        wg.pfor(12 * Nxy + 6 * Nyaw, [&](int t) { if (t < 12 * Nxy) oc[t] = cxy[t]; else oy[t - 12 * Nxy] = cyaw[t - 12 * Nxy]; });
         wg.pfor(1, [&](int) {
             st.T_xy = Txy; st.T_yaw = Tyaw; st.jerk_cost = last_jerk; st.scale_fx = scale_fx; st.rho = rho;
             st.evals = evals; st.hist_reads = hist_reads;
@@ -1400,10 +1389,7 @@ struct Solver {
     UPH_HD void report(const TrajState& st) {
         const double* oc = bd.cxy + td.off_cxy;
         const double* oy = bd.cyaw + td.off_cyaw;
-        wg.pfor(12 * Nxy + 6 * Nyaw, [&](int t) {
-            if (t < 12 * Nxy) { const int i = t / 12, r = t - 12 * i; cxy[(r >> 1) * sxy + 2 * i + (r & 1)] = oc[t]; }
-            else { const int u = t - 12 * Nxy, m = u / 6, k = u - 6 * m; cyaw[k * syw + m] = oy[u]; }
-        });
+        wg.pfor(12 * Nxy + 6 * Nyaw, [&](int t) { if (t < 12 * Nxy) cxy[t] = oc[t]; else cyaw[t - 12 * Nxy] = oy[t - 12 * Nxy]; });
         const double Tx = st.T_xy, Ty = st.T_yaw;
         double durx = 0.0, dury = 0.0;
         for (int i = 0; i < Nxy; i++) durx += Tx;
@@ -1436,20 +1422,20 @@ struct Solver {
             if (iw == Nyaw) { iw--; tw += Ty; }
             double p[2], v[2], a[2];
             for (int dd = 0; dd < 2; dd++) {
-                const double* c = cxy + 2 * ix + dd;
+                const double* c = cxy + 12 * ix + dd;
                 double val = 0, tn = 1.0;
-                for (int kk = 0; kk <= 5; kk++) { val += tn * c[kk * sxy]; tn *= tl; }
+                for (int kk = 0; kk <= 5; kk++) { val += tn * c[kk * 2]; tn *= tl; }
                 double dv = 0; tn = 1.0;
-                for (int kk = 1; kk <= 5; kk++) { dv += kk * tn * c[kk * sxy]; tn *= tl; }
+                for (int kk = 1; kk <= 5; kk++) { dv += kk * tn * c[kk * 2]; tn *= tl; }
                 double da = 0; tn = 1.0;
-                for (int kk = 2; kk <= 5; kk++) { da += (kk - 1) * kk * tn * c[kk * sxy]; tn *= tl; }
+                for (int kk = 2; kk <= 5; kk++) { da += (kk - 1) * kk * tn * c[kk * 2]; tn *= tl; }
                 p[dd] = val; v[dd] = dv; a[dd] = da;
             }
-            const double* c = cyaw + iw;
+            const double* c = cyaw + 6 * iw;
             double yaw = 0, tn = 1.0;
-            for (int kk = 0; kk <= 5; kk++) { yaw += tn * c[kk * syw]; tn *= tw; }
+            for (int kk = 0; kk <= 5; kk++) { yaw += tn * c[kk]; tn *= tw; }
             double dyaw = 0; tn = 1.0;
-            for (int kk = 1; kk <= 5; kk++) { dyaw += kk * tn * c[kk * syw]; tn *= tw; }
+            for (int kk = 1; kk <= 5; kk++) { dyaw += kk * tn * c[kk]; tn *= tw; }
             const double yawn = normSO2(yaw);
             double cy_, sy_;
             sincosFast(yaw, sy_, cy_);

@@ -151,10 +151,10 @@ struct DevWG {
 #define UPH_MFMA_SCATTER 1
 #endif
     static constexpr bool MFMA_SCATTER = UPH_MFMA_SCATTER != 0;
-    __device__ __forceinline__ void scatterXY17(const double* rec, const double* wtab, double* Gxy, int sxy_, int i0_, int P_, int s0_, int cnt_) {
+    __device__ __forceinline__ void scatterXY17(const double* rec, const double* wtab, double* Gxy, int i0_, int P_, int s0_, int cnt_) {
         typedef double d4_t __attribute__((ext_vector_type(4)));
         constexpr int K1 = 17, NQ = 3 * K1, CHP = NT + 1;
-        const int P = uni(P_), s0 = uni(s0_), cnt = uni(cnt_), i0 = uni(i0_), sxy = uni(sxy_);
+        const int P = uni(P_), s0 = uni(s0_), cnt = uni(cnt_), i0 = uni(i0_);
         const int ntile = (2 * P + 15) >> 4;
         const int ln = flane();
         const int c = ln & 15, kk = (ln >> 4) & 3;
@@ -181,9 +181,9 @@ struct DevWG {
                 else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
             }
             if (pi < P) {
-                double* gp = Gxy + 2 * (i0 + pi) + dd;                   // K-major G: row k of (piece, dim) at k * sxy (the 16 columns of a tile are 16 consecutive doubles)
-                gp[kk * sxy] += acc0[0] + acc1[0];                       // row kk
-                if (kk < 2) gp[(4 + kk) * sxy] += acc0[1] + acc1[1];     // rows 4, 5
+                double* gp = Gxy + 12 * (i0 + pi) + dd;
+                gp[2 * kk] += acc0[0] + acc1[0];                         // row kk
+                if (kk < 2) gp[2 * (4 + kk)] += acc0[1] + acc1[1];       // rows 4, 5
             }
         }
     }
@@ -457,7 +457,8 @@ struct DevWG {
         const int len = LAYOUT == 0 ? uni(lenW_) : (LAYOUT == 1 ? uni(lenX_) : (isw ? uni(lenW_) : uni(lenX_)));
         const int j0 = KPL * hl + 1;                            // the lane's first knot, 1-based
         const int ks = isw ? 2 : 4, cs = isw ? 1 : 2;           // knot / component strides of the buffer
-        double* pk = isw ? bw + (size_t)(j0 - 1) * 2 : bx + (size_t)(j0 - 1) * 4 + dd;
+        static_assert(KPL == THOMAS_KPL, "the knot buffers are padded per block of THOMAS_KPL knots (uph_common.hpp knotOff)");
+        double* pk = isw ? bw + knotOff(j0 - 1, 2) : bx + knotOff(j0 - 1, 4) + dd;      // the lane's block: KPL knots back to back (no pad inside a block)
         const int lmax = LAYOUT == 0 ? uni(lenW_) : (LAYOUT == 1 ? uni(lenX_) : (uni(lenW_) > uni(lenX_) ? uni(lenW_) : uni(lenX_)));
         double c[KPL][2], F[KPL][4], Qm[KPL][4], M2[KPL][4];
         // ---- forward composition (ascending knots)

@@ -204,6 +204,16 @@ UPH_HD int histRowDoubles(int n) { return 2 + 128 * histNQ(n); }
 constexpr int THOMAS_J = 26;
 constexpr int THOMAS_STRIDE = 8;
 constexpr int THOMAS_DOUBLES = (THOMAS_J + 1) * THOMAS_STRIDE;
+// Knot buffers of the MINCO solve in LDS.  The blocked sweeps (DevWG::thomasWave) give every lane THOMAS_KPL consecutive knots; with the knots packed
+// back to back a lane's block starts 4 KPL doubles (xy: 128 bytes, half the 256-byte LDS bank row) after its neighbour's, so the 32 lanes of a
+// ds_read_b64 group hit TWO bank positions -- 16-way replays on every load and store of the solve (the largest single source of the penalty kernel's
+// LDS bank conflicts, profiles/r05c_lds_knot_buffers.txt).  One pad double after every block makes the lane stride an odd number of doubles: knot q
+// (0-based along its chain, ks doubles per knot) sits at knotOff(q, ks); the buffers of generate(), which also hold the two end knots, index by
+// j = q + 1 through knotOffJ.  Producers and consumers (right-hand sides, Hermite expansion, adjoint) use the same two functions.
+constexpr int THOMAS_KPL = 4;
+UPH_HD int knotOff(int q, int ks) { return ks * q + (q >> 2); }
+UPH_HD int knotOffJ(int j, int ks) { return ks * j + ((j + 3) >> 2); }        // knotOffJ(q + 1, ks) - knotOffJ(1, ks) == knotOff(q, ks); knotOffJ(0, ks) == 0
+UPH_HD int knotBufDoubles(int nknots, int ks) { return ks * nknots + (nknots >> 2) + 2; }
 // the four 2x2 matrices of knot j for the forward (M z = r) or adjoint (M^T lambda = g) sweeps, C = [8 -1; -7 1]
 template <bool ADJ>
 UPH_HD void thomasFactors(const double* tab, int j, double* P, double* M1, double* Q, double* M2) {
