@@ -127,4 +127,20 @@ done 2>&1 | tee $OUT/ab.txt
 unset UNEVENHIP_LIB
 bash tools/pmc_eval.sh r05d default lds 2>&1 | grep SQ_
 ;;
+5)
+# tuning A/B with the timers off: two-loop prefetch depth 4 / 5 (default) / 6, grid descriptor held in SGPRs instead of re-read per sample chunk
+OUT=gpurun_out/r05e; mkdir -p $OUT
+for v in default pf4 pf6 gridsgpr default pf4 pf6 gridsgpr; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu --no-extras > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  python - $OUT/bench_$v.json $v <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+    print('%-10s value %.0f traj/s  launch %.1f ms  frac %.3f  converged %.3f  single traj %.2f ms' % (sys.argv[2], r['value'], r['roofline']['avg_launch_ms'], r['roofline']['frac'], r['converged_frac'], r['single_traj_ms']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e, open(sys.argv[1].replace('.json', '.err')).read()[-400:])
+PY
+done 2>&1 | tee $OUT/ab.txt
+;;
 esac
