@@ -2,6 +2,7 @@
 # The GPU-box command lists of round 5's gpurun calls, one case per call: gpurun -- "bash tools/r05_runs.sh <n>".
 set -u
 cd $GRAFT_REPO_ROOT
+export UPH_GIT_HEAD=$(cat build/git_head.txt 2>/dev/null || echo unknown)      # (the GPU box holds a snapshot without .git: `git rev-parse --short HEAD > build/git_head.txt` before the call)
 make -C oracle -s 2>&1 | tail -2
 case "${1:-}" in
 1)
@@ -151,5 +152,13 @@ python __graft_entry__.py smoke 2>&1 | tail -2 | tee $OUT/smoke.txt
 timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
 tail -4 $OUT/gpu_tests.txt | cut -c1-300
 bash tools/profile.sh $TAG 2>&1 | tail -40 | cut -c1-300
+;;
+7)
+# the bench line alone, for the record (profiles/<tag>_bench.json)
+TAG=${2:-r05g}
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?"
+tail -c 400 $OUT/bench.json; echo
+timeout 600 python bench.py --workload km2 --steps 3 --warmup 1 > $OUT/bench_km2.json 2> $OUT/bench_km2.err; echo "km2 rc $?"
 ;;
 esac

@@ -348,6 +348,9 @@ __global__ __launch_bounds__(64, WPS) void uph_kino_kernel(GridDev g, const char
     const int lane = threadIdx.x;
     const KinoDev& P = *Pp;
     KNode* nodes = W.nodes + (size_t)blockIdx.x * node_stride;
+    // gfx950 only (like the whole library: Makefile ARCH): the residency these sizes aim at -- 16 one-wave blocks per CU in the default WPS = 4 form, which is
+    // what the automatic workspace count of uph_kino_create provides -- needs the 160 KB of LDS per CU of this part (16 x 8 KB); a part with 64 KB would hold half
+    // as many.  The WPS = 6 / 8 forms are experiment knobs: they run with the same workspaces (at most 16 resident queries per CU), not with more.
     constexpr int TOPN = WPS <= 2 ? 1023 : (WPS <= 4 ? 511 : 255);      // 16 / 8 / 4 KB of LDS per wave: 8 / 16 / 24-32 waves per CU
     __shared__ KHeap heap_top[TOPN];
     const KHeapRef<TOPN> heap = {heap_top, W.heap + (size_t)blockIdx.x * heap_stride};

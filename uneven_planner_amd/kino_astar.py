@@ -67,8 +67,10 @@ class KinoAstar:
         except Exception:
             pass
 
-    def plan_batch(self, starts, goals, path_cap=1024, max_expand=0, exp_cap=0):
-        """B queries at once: list of dict(status, path (n,3), n_path, iter_num, use_node_num[, expanded (k,3)])"""
+    def plan_batch(self, starts, goals, path_cap=1024, max_expand=0, exp_cap=0, complete=True):
+        """B queries at once: list of dict(status, path (n,3), n_path, iter_num, use_node_num[, expanded (k,3)]).  complete: a front_end_path longer than
+        path_cap is searched again with room for all its poses (the reference returns the whole path); False leaves it clipped at path_cap poses with
+        n_path telling its real length (throughput measurements that bound the download)"""
         s = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
         g = np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 3)
         B = s.shape[0]
@@ -86,7 +88,7 @@ class KinoAstar:
             out.append(r)
         # a front_end_path longer than path_cap was clipped by the library (the node chain comes first, the Dubins shot that reaches the goal
         # last): the reference returns the whole path, so those queries are searched again with room for all their poses
-        longer = [b for b in range(B) if st[b] == 0 and npth[b] > path_cap] if (path_cap > 1 and max_expand == 0) else []
+        longer = [b for b in range(B) if st[b] == 0 and npth[b] > path_cap] if (complete and path_cap > 1 and max_expand == 0) else []
         if longer:
             again = self.plan_batch(s[longer], g[longer], path_cap=int(npth[longer].max()), max_expand=0, exp_cap=0)
             for b, r2 in zip(longer, again):
