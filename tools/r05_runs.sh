@@ -161,4 +161,28 @@ python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "
 tail -c 400 $OUT/bench.json; echo
 timeout 600 python bench.py --workload km2 --steps 3 --warmup 1 > $OUT/bench_km2.json 2> $OUT/bench_km2.err; echo "km2 rc $?"
 ;;
+8)
+# initScaling with the operator rows fetched once for all seven constraints of a sample (sg1) / once per group of four and three (default): bit identity,
+# scaling-kernel time, init-scaling tests
+OUT=gpurun_out/r05h; mkdir -p $OUT
+python tools/cmp_variant.py $OUT/x_default.npy 2>&1 | tail -1
+UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_r04.so python tools/cmp_variant.py $OUT/x_r04.npy 2>&1 | tail -1
+python -c "
+import numpy as np
+a, b = np.load('$OUT/x_default.npy'), np.load('$OUT/x_r04.npy')
+print('hill, 64 solves: this build vs round 4 library: bit-identical', np.array_equal(a, b), 'max diff', np.abs(a-b).max())" | tee $OUT/bit_identity.txt
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_lanes.py tests/test_gpu_edge.py -m gpu -q 2>&1 | tail -3
+for v in sg3 default sg3 default; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu --no-extras > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  python - $OUT/bench_$v.json $v <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+    print('%-10s value %.0f traj/s  step %.1f ms  launch %.1f ms  scaling kernel %.2f ms  single traj %.2f ms' % (sys.argv[2], r['value'], r['ms_per_step'], r['roofline']['avg_launch_ms'], r['scaling_kernel_ms'], r['single_traj_ms']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e, open(sys.argv[1].replace('.json', '.err')).read()[-400:])
+PY
+done 2>&1 | tee $OUT/ab.txt
+;;
 esac

@@ -889,161 +889,222 @@ struct Solver {
         wg.pfor(S, [&](int s) { scalingSample(s, dTau); });
     }
 
-    // one sample of the per-constraint scaling loop of initScaling
+    // one sample of the per-constraint scaling loop of initScaling.  The seven constraints of a sample read the SAME operator rows (those of the
+    // sample's two knots): the rows are fetched once per batch of eight columns and applied to all seven weight sets (until round 5 every constraint
+    // fetched them again: seven times the loads and their round trips); per constraint the arithmetic and its order are unchanged.
     UPH_HD void scalingSample(int s, double dTau) {
+        const int i = divSmall(s, K + 1, inv_k1), j = s - i * (K + 1);
+        Kin k;
+        kin(i, j, k);
+        // two groups of constraints (the rows are fetched twice per sample instead of seven times): all seven at once keep 150 doubles of per-constraint
+        // state live next to the sample's kinematics and spill 340 registers even without a register cap (UPH_SCALING_GROUPS = 1: 8.8 ms per launch of
+        // 16384 against 10.4 ms for the per-constraint form)
+#if !defined(UPH_SCALING_GROUPS) || UPH_SCALING_GROUPS == 2
+        scalingGroup<0, 4>(s, i, j, k, dTau);
+        scalingGroup<4, 3>(s, i, j, k, dTau);
+#elif UPH_SCALING_GROUPS == 3
+        scalingGroup<0, 3>(s, i, j, k, dTau);
+        scalingGroup<3, 2>(s, i, j, k, dTau);
+        scalingGroup<5, 2>(s, i, j, k, dTau);
+#else
+        scalingGroup<0, 7>(s, i, j, k, dTau);
+#endif
+    }
+    template <int Q0, int NQS>
+    UPH_HD void scalingGroup(int s, int i, int j, const Kin& k, double dTau) {
         const int nbx = Nxy + 5, nby = Nyaw + 5;
         const double Tx = Txy, Ty = Tyaw, itx = 1.0 / Txy, ity = 1.0 / Tyaw;
         const double gravity = grid.gravity;
-            const int i = divSmall(s, K + 1, inv_k1), j = s - i * (K + 1);
-            Kin k;
-            kin(i, j, k);
-            const double alpha = 1.0 / K * j;
-            const double icvx = k.tv[0], icvy = k.tv[2], icxi = k.tv[5];
-            const int m = k.yaw_idx;
-            for (int q = 0; q < 7; q++) {
-                double gp_[2] = {0, 0}, gv_[2] = {0, 0}, ga_[2] = {0, 0}, gyaw = 0.0, gdyaw = 0.0, gse2[3];
-                if (q == 0) {                    // non-holonomic :521-529
-                    gv_[0] = k.syaw; gv_[1] = -k.cyaw;
-                    gyaw = k.vel[0] * k.cyaw + k.vel[1] * k.syaw;
-                } else if (q == 1) {             // longitude velocity :531-544
-                    for (int t = 0; t < 2; t++) gv_[t] = 1.0 * icvx * icvx * 2.0 * k.vel[t];
-                    for (int t = 0; t < 3; t++) gse2[t] = 1.0 * k.v_norm * k.v_norm * 2.0 * icvx * k.tg[0][t];
-                    gp_[0] = gse2[0]; gp_[1] = gse2[1]; gyaw = gse2[2];
-                } else if (q == 2) {             // longitude acceleration :546-560
-                    const double gax = 2.0 * k.ax;
-                    ga_[0] = gax * icvx * k.cyaw; ga_[1] = gax * icvx * k.syaw;
-                    gyaw = gax * icvx * k.lat_acc;
-                    for (int t = 0; t < 3; t++) gse2[t] = gax * (gravity * k.tg[1][t] + k.tg[0][t] * k.lon_acc);
-                    gp_[0] = gse2[0]; gp_[1] = gse2[1]; gyaw += gse2[2];
-                } else if (q == 3) {             // latitude acceleration :562-576
-                    const double gay = 2.0 * k.ay;
-                    ga_[0] = gay * icvy * (-k.syaw); ga_[1] = gay * icvy * k.cyaw;
-                    gyaw = -gay * icvy * k.lon_acc;
-                    for (int t = 0; t < 3; t++) gse2[t] = gay * (gravity * k.tg[3][t] + k.tg[2][t] * k.lat_acc);
-                    gp_[0] = gse2[0]; gp_[1] = gse2[1]; gyaw += gse2[2];
-                } else if (q == 4) {             // curvature :578-598
-                    const double den = 1.0 / (k.vx * k.vx + delta_sigl);
-                    const double gwz = den * 2.0 * k.wz;
-                    const double gvx2 = -k.curv_snorm * den;
-                    gdyaw = gwz * icxi;
-                    for (int t = 0; t < 3; t++) gse2[t] = gwz * k.dyaw * k.tg[5][t];
-                    for (int t = 0; t < 2; t++) gv_[t] = gvx2 * icvx * icvx * 2.0 * k.vel[t];
-                    for (int t = 0; t < 3; t++) gse2[t] += gvx2 * k.v_norm * k.v_norm * 2.0 * icvx * k.tg[0][t];
-                    gp_[0] = gse2[0]; gp_[1] = gse2[1]; gyaw = gse2[2];
-                } else if (q == 5) {             // attitude :600-609
-                    gp_[0] = -k.tg[4][0]; gp_[1] = -k.tg[4][1]; gyaw = -k.tg[4][2];
-                } else {                         // surface variation :611-620
-                    gp_[0] = k.tg[6][0]; gp_[1] = k.tg[6][1]; gyaw = k.tg[6][2];
-                }
-                // sparse dc_i/dC blocks, already multiplied by T^-k, and the chain term -k c/T
-                double gx_[6][2], gy_[6];
-                double chain_x = 0.0, chain_y = 0.0, sx = 1.0, sy = 1.0;
-                for (int kk = 0; kk < 6; kk++) {
-                    for (int t = 0; t < 2; t++) {
-                        const double v = k.b0[kk] * gp_[t] + k.b1[kk] * gv_[t] + k.b2[kk] * ga_[t];
-                        chain_x += -(double)kk * cxy[12 * i + kk * 2 + t] * itx * v;
-                        gx_[kk][t] = v * sx;
-                    }
-                    const double vy = k.y0[kk] * gyaw + k.y1[kk] * gdyaw;
-                    chain_y += -(double)kk * cyaw[6 * m + kk] * ity * vy;
-                    gy_[kk] = vy * sy;
-                    sx *= itx; sy *= ity;
-                }
-                double tx = ((gp_[0] * k.vel[0] + gp_[1] * k.vel[1]) + (gv_[0] * k.acc[0] + gv_[1] * k.acc[1]) + (ga_[0] * k.jer[0] + ga_[1] * k.jer[1])) * alpha;
-                const double yawdot = gyaw * k.dyaw + gdyaw * k.d2yaw;
-                tx += yawdot * (alpha + i);
-                const double ty = -yawdot * m;
-                double mx = 0.0, headtail_x = 0.0, headtail_y = 0.0;
-                // M^T restricted to this sample's piece = (transposed Hermite expansion to the piece's two knots) followed by the
-                // knot operator rows of those knots (interior ones) or the direct beta columns (end knots, all positions)
-                double dpL[2], dvL[2], daL[2], dpR[2], dvR[2], daR[2];
-                for (int t = 0; t < 2; t++) {
-                    const double g0 = gx_[0][t], g1 = gx_[1][t], g2 = gx_[2][t], g3 = gx_[3][t], g4 = gx_[4][t], g5 = gx_[5][t];
-                    dpL[t] = g0 - 10.0 * g3 + 15.0 * g4 - 6.0 * g5; dvL[t] = g1 - 6.0 * g3 + 8.0 * g4 - 3.0 * g5; daL[t] = 0.5 * g2 - 1.5 * g3 + 1.5 * g4 - 0.5 * g5;
-                    dpR[t] = 10.0 * g3 - 15.0 * g4 + 6.0 * g5; dvR[t] = -4.0 * g3 + 7.0 * g4 - 3.0 * g5; daR[t] = 0.5 * g3 - g4 + 0.5 * g5;
-                }
-                // Only the way-point columns (max norm) and the four head/tail V, A columns (time gradient) are needed.  Operator
-                // rows are read in unconditional batches of 8 columns (end knots carry zero weights instead of branches): a loop
-                // with one dependent load per column pays one L2 round trip per column (the old form: 1700 round trips per sample).
-                const bool inL = i >= 1, inR = i + 1 <= Nxy - 1;
-                const auto WL = UPH_AS_GLOBAL(Wr_xy + (size_t)(inL ? 2 * (i - 1) : 0) * nbx);      // rows v_i, a_i
-                const auto WR = UPH_AS_GLOBAL(Wr_xy + (size_t)(inR ? 2 * i : 0) * nbx);            // rows v_{i+1}, a_{i+1}
-                const int pcL = knotCol(i, Nxy), pcR = knotCol(i + 1, Nxy);
-                double cw[4][2];                                  // weights of rows (v_L, a_L, v_R, a_R); zero for an end knot
-                for (int t = 0; t < 2; t++) { cw[0][t] = inL ? dvL[t] : 0.0; cw[1][t] = inL ? daL[t] : 0.0; cw[2][t] = inR ? dvR[t] : 0.0; cw[3][t] = inR ? daR[t] : 0.0; }
-                for (int c0 = 3; c0 < Nxy + 2; c0 += 8) {
-                    double w[4][8];
+        const double alpha = 1.0 / K * j;
+        const double icvx = k.tv[0], icvy = k.tv[2], icxi = k.tv[5];
+        const int m = k.yaw_idx;
+        // per constraint: the transposed Hermite expansion of its sparse dc/dC blocks to the piece's two knots (xy: dp / dv / da at the left and right
+        // knot per dimension; yaw alike) and the scalar parts of its time gradient
+        double dpL[NQS][2], dvL[NQS][2], daL[NQS][2], dpR[NQS][2], dvR[NQS][2], daR[NQS][2];
+        double ypL[NQS], yvL[NQS], yaL[NQS], ypR[NQS], yvR[NQS], yaR[NQS];
+        double sumx[NQS], sumy[NQS], mx[NQS];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int cc = c0 + u < Nxy + 2 ? c0 + u : Nxy + 1;
-                        w[0][u] = WL[cc]; w[1][u] = WL[nbx + cc]; w[2][u] = WR[cc]; w[3][u] = WR[nbx + cc];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int col = c0 + u;
-                        double a0 = (w[0][u] * cw[0][0] + w[1][u] * cw[1][0]) + (w[2][u] * cw[2][0] + w[3][u] * cw[3][0]);
-                        double a1 = (w[0][u] * cw[0][1] + w[1][u] * cw[1][1]) + (w[2][u] * cw[2][1] + w[3][u] * cw[3][1]);
-                        if (col == pcL) { a0 += dpL[0]; a1 += dpL[1]; }
-                        if (col == pcR) { a0 += dpR[0]; a1 += dpR[1]; }
-                        if (col < Nxy + 2) mx = dmax(mx, dmax(fabs(a0), fabs(a1)));
-                    }
-                }
-                {
-                    const int sc[4] = {1, 2, Nxy + 3, Nxy + 4};
-                    double w[4][4], a0[4], a1[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { w[0][u] = WL[sc[u]]; w[1][u] = WL[nbx + sc[u]]; w[2][u] = WR[sc[u]]; w[3][u] = WR[nbx + sc[u]]; }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        a0[u] = (w[0][u] * cw[0][0] + w[1][u] * cw[1][0]) + (w[2][u] * cw[2][0] + w[3][u] * cw[3][0]);
-                        a1[u] = (w[0][u] * cw[0][1] + w[1][u] * cw[1][1]) + (w[2][u] * cw[2][1] + w[3][u] * cw[3][1]);
-                    }
-                    if (!inL) { a0[0] += dvL[0]; a1[0] += dvL[1]; a0[1] += daL[0]; a1[1] += daL[1]; }      // an end knot's V, A are beta columns themselves
-                    if (!inR) { a0[2] += dvR[0]; a1[2] += dvR[1]; a0[3] += daR[0]; a1[3] += daR[1]; }
-                    headtail_x += a0[0] * hd[2] + a1[0] * hd[3];
-                    headtail_x += 2.0 * Tx * (a0[1] * hd[4] + a1[1] * hd[5]);
-                    headtail_x += a0[2] * hd[8] + a1[2] * hd[9];
-                    headtail_x += 2.0 * Tx * (a0[3] * hd[10] + a1[3] * hd[11]);
-                }
-                {
-                    const double g0 = gy_[0], g1 = gy_[1], g2 = gy_[2], g3 = gy_[3], g4 = gy_[4], g5 = gy_[5];
-                    const double ypL = g0 - 10.0 * g3 + 15.0 * g4 - 6.0 * g5, yvL = g1 - 6.0 * g3 + 8.0 * g4 - 3.0 * g5, yaL = 0.5 * g2 - 1.5 * g3 + 1.5 * g4 - 0.5 * g5;
-                    const double ypR = 10.0 * g3 - 15.0 * g4 + 6.0 * g5, yvR = -4.0 * g3 + 7.0 * g4 - 3.0 * g5, yaR = 0.5 * g3 - g4 + 0.5 * g5;
-                    const bool yL = m >= 1, yR = m + 1 <= Nyaw - 1;
-                    const auto VL = UPH_AS_GLOBAL(Wr_yaw + (size_t)(yL ? 2 * (m - 1) : 0) * nby);
-                    const auto VR = UPH_AS_GLOBAL(Wr_yaw + (size_t)(yR ? 2 * m : 0) * nby);
-                    const int qL = knotCol(m, Nyaw), qR = knotCol(m + 1, Nyaw);
-                    const double yw[4] = {yL ? yvL : 0.0, yL ? yaL : 0.0, yR ? yvR : 0.0, yR ? yaR : 0.0};
-                    for (int c0 = 3; c0 < Nyaw + 2; c0 += 8) {
-                        double w[4][8];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            const int cc = c0 + u < Nyaw + 2 ? c0 + u : Nyaw + 1;
-                            w[0][u] = VL[cc]; w[1][u] = VL[nby + cc]; w[2][u] = VR[cc]; w[3][u] = VR[nby + cc];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            const int col = c0 + u;
-                            double a0 = (w[0][u] * yw[0] + w[1][u] * yw[1]) + (w[2][u] * yw[2] + w[3][u] * yw[3]);
-                            if (col == qL) a0 += ypL;
-                            if (col == qR) a0 += ypR;
-                            if (col < Nyaw + 2) mx = dmax(mx, fabs(a0));
-                        }
-                    }
-                    const int sc[4] = {1, 2, Nyaw + 3, Nyaw + 4};
-                    double a0[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) a0[u] = (VL[sc[u]] * yw[0] + VL[nby + sc[u]] * yw[1]) + (VR[sc[u]] * yw[2] + VR[nby + sc[u]] * yw[3]);
-                    if (!yL) { a0[0] += yvL; a0[1] += yaL; }
-                    if (!yR) { a0[2] += yvR; a0[3] += yaR; }
-                    headtail_y += a0[0] * hd[13];
-                    headtail_y += 2.0 * Ty * a0[1] * hd[14];
-                    headtail_y += a0[2] * hd[16];
-                    headtail_y += 2.0 * Ty * a0[3] * hd[17];
-                }
-                const double gTau = ((tx + chain_x + headtail_x) / Nxy + (ty + chain_y + headtail_y) / Nyaw) * dTau;   // :642-644
-                scl[q * S + s] = 1.0 / dmax(1.0, dmax(mx, fabs(gTau)));                                                // :658-659
+        for (int qi = 0; qi < NQS; qi++) {
+            const int q = Q0 + qi;                   // the constraint (alm_traj_opt.cpp:521-620)
+            double gp_[2] = {0, 0}, gv_[2] = {0, 0}, ga_[2] = {0, 0}, gyaw = 0.0, gdyaw = 0.0, gse2[3];
+            if (q == 0) {                    // non-holonomic :521-529
+                gv_[0] = k.syaw; gv_[1] = -k.cyaw;
+                gyaw = k.vel[0] * k.cyaw + k.vel[1] * k.syaw;
+            } else if (q == 1) {             // longitude velocity :531-544
+                for (int t = 0; t < 2; t++) gv_[t] = 1.0 * icvx * icvx * 2.0 * k.vel[t];
+                for (int t = 0; t < 3; t++) gse2[t] = 1.0 * k.v_norm * k.v_norm * 2.0 * icvx * k.tg[0][t];
+                gp_[0] = gse2[0]; gp_[1] = gse2[1]; gyaw = gse2[2];
+            } else if (q == 2) {             // longitude acceleration :546-560
+                const double gax = 2.0 * k.ax;
+                ga_[0] = gax * icvx * k.cyaw; ga_[1] = gax * icvx * k.syaw;
+                gyaw = gax * icvx * k.lat_acc;
+                for (int t = 0; t < 3; t++) gse2[t] = gax * (gravity * k.tg[1][t] + k.tg[0][t] * k.lon_acc);
+                gp_[0] = gse2[0]; gp_[1] = gse2[1]; gyaw += gse2[2];
+            } else if (q == 3) {             // latitude acceleration :562-576
+                const double gay = 2.0 * k.ay;
+                ga_[0] = gay * icvy * (-k.syaw); ga_[1] = gay * icvy * k.cyaw;
+                gyaw = -gay * icvy * k.lon_acc;
+                for (int t = 0; t < 3; t++) gse2[t] = gay * (gravity * k.tg[3][t] + k.tg[2][t] * k.lat_acc);
+                gp_[0] = gse2[0]; gp_[1] = gse2[1]; gyaw += gse2[2];
+            } else if (q == 4) {             // curvature :578-598
+                const double den = 1.0 / (k.vx * k.vx + delta_sigl);
+                const double gwz = den * 2.0 * k.wz;
+                const double gvx2 = -k.curv_snorm * den;
+                gdyaw = gwz * icxi;
+                for (int t = 0; t < 3; t++) gse2[t] = gwz * k.dyaw * k.tg[5][t];
+                for (int t = 0; t < 2; t++) gv_[t] = gvx2 * icvx * icvx * 2.0 * k.vel[t];
+                for (int t = 0; t < 3; t++) gse2[t] += gvx2 * k.v_norm * k.v_norm * 2.0 * icvx * k.tg[0][t];
+                gp_[0] = gse2[0]; gp_[1] = gse2[1]; gyaw = gse2[2];
+            } else if (q == 5) {             // attitude :600-609
+                gp_[0] = -k.tg[4][0]; gp_[1] = -k.tg[4][1]; gyaw = -k.tg[4][2];
+            } else {                         // surface variation :611-620
+                gp_[0] = k.tg[6][0]; gp_[1] = k.tg[6][1]; gyaw = k.tg[6][2];
             }
+            // sparse dc_i/dC blocks, already multiplied by T^-k, and the chain term -k c/T
+            double gx_[6][2], gy_[6];
+            double chain_x = 0.0, chain_y = 0.0, sx = 1.0, sy = 1.0;
+            for (int kk = 0; kk < 6; kk++) {
+                for (int t = 0; t < 2; t++) {
+                    const double v = k.b0[kk] * gp_[t] + k.b1[kk] * gv_[t] + k.b2[kk] * ga_[t];
+                    chain_x += -(double)kk * cxy[12 * i + kk * 2 + t] * itx * v;
+                    gx_[kk][t] = v * sx;
+                }
+                const double vy = k.y0[kk] * gyaw + k.y1[kk] * gdyaw;
+                chain_y += -(double)kk * cyaw[6 * m + kk] * ity * vy;
+                gy_[kk] = vy * sy;
+                sx *= itx; sy *= ity;
+            }
+            double tx = ((gp_[0] * k.vel[0] + gp_[1] * k.vel[1]) + (gv_[0] * k.acc[0] + gv_[1] * k.acc[1]) + (ga_[0] * k.jer[0] + ga_[1] * k.jer[1])) * alpha;
+            const double yawdot = gyaw * k.dyaw + gdyaw * k.d2yaw;
+            tx += yawdot * (alpha + i);
+            const double ty = -yawdot * m;
+            sumx[qi] = tx + chain_x;
+            sumy[qi] = ty + chain_y;
+            mx[qi] = 0.0;
+            // M^T restricted to this sample's piece = (transposed Hermite expansion to the piece's two knots) followed by the
+            // knot operator rows of those knots (interior ones) or the direct beta columns (end knots, all positions)
+            for (int t = 0; t < 2; t++) {
+                const double g0 = gx_[0][t], g1 = gx_[1][t], g2 = gx_[2][t], g3 = gx_[3][t], g4 = gx_[4][t], g5 = gx_[5][t];
+                dpL[qi][t] = g0 - 10.0 * g3 + 15.0 * g4 - 6.0 * g5; dvL[qi][t] = g1 - 6.0 * g3 + 8.0 * g4 - 3.0 * g5; daL[qi][t] = 0.5 * g2 - 1.5 * g3 + 1.5 * g4 - 0.5 * g5;
+                dpR[qi][t] = 10.0 * g3 - 15.0 * g4 + 6.0 * g5; dvR[qi][t] = -4.0 * g3 + 7.0 * g4 - 3.0 * g5; daR[qi][t] = 0.5 * g3 - g4 + 0.5 * g5;
+            }
+            {
+                const double g0 = gy_[0], g1 = gy_[1], g2 = gy_[2], g3 = gy_[3], g4 = gy_[4], g5 = gy_[5];
+                ypL[qi] = g0 - 10.0 * g3 + 15.0 * g4 - 6.0 * g5; yvL[qi] = g1 - 6.0 * g3 + 8.0 * g4 - 3.0 * g5; yaL[qi] = 0.5 * g2 - 1.5 * g3 + 1.5 * g4 - 0.5 * g5;
+                ypR[qi] = 10.0 * g3 - 15.0 * g4 + 6.0 * g5; yvR[qi] = -4.0 * g3 + 7.0 * g4 - 3.0 * g5; yaR[qi] = 0.5 * g3 - g4 + 0.5 * g5;
+            }
+        }
+        // ---- position blocks.  Only the way-point columns (max norm) and the four head/tail V, A columns (time gradient) are needed.  Operator
+        // rows are read in unconditional batches of 8 columns (end knots carry zero weights instead of branches): a loop with one dependent load
+        // per column pays one L2 round trip per column (the old form: 1700 round trips per sample).
+        const bool inL = i >= 1, inR = i + 1 <= Nxy - 1;
+        const auto WL = UPH_AS_GLOBAL(Wr_xy + (size_t)(inL ? 2 * (i - 1) : 0) * nbx);      // rows v_i, a_i
+        const auto WR = UPH_AS_GLOBAL(Wr_xy + (size_t)(inR ? 2 * i : 0) * nbx);            // rows v_{i+1}, a_{i+1}
+        const int pcL = knotCol(i, Nxy), pcR = knotCol(i + 1, Nxy);
+        for (int c0 = 3; c0 < Nxy + 2; c0 += 8) {
+            double w[4][8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int cc = c0 + u < Nxy + 2 ? c0 + u : Nxy + 1;
+                w[0][u] = WL[cc]; w[1][u] = WL[nbx + cc]; w[2][u] = WR[cc]; w[3][u] = WR[nbx + cc];
+            }
+#pragma unroll
+            for (int q = 0; q < NQS; q++) {
+                // weights of rows (v_L, a_L, v_R, a_R); zero for an end knot
+                const double c00 = inL ? dvL[q][0] : 0.0, c01 = inL ? dvL[q][1] : 0.0, c10 = inL ? daL[q][0] : 0.0, c11 = inL ? daL[q][1] : 0.0;
+                const double c20 = inR ? dvR[q][0] : 0.0, c21 = inR ? dvR[q][1] : 0.0, c30 = inR ? daR[q][0] : 0.0, c31 = inR ? daR[q][1] : 0.0;
+                double mq = mx[q];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int col = c0 + u;
+                    double a0 = (w[0][u] * c00 + w[1][u] * c10) + (w[2][u] * c20 + w[3][u] * c30);
+                    double a1 = (w[0][u] * c01 + w[1][u] * c11) + (w[2][u] * c21 + w[3][u] * c31);
+                    if (col == pcL) { a0 += dpL[q][0]; a1 += dpL[q][1]; }
+                    if (col == pcR) { a0 += dpR[q][0]; a1 += dpR[q][1]; }
+                    if (col < Nxy + 2) mq = dmax(mq, dmax(fabs(a0), fabs(a1)));
+                }
+                mx[q] = mq;
+            }
+        }
+        double htx[NQS], hty[NQS];
+        {
+            const int sc[4] = {1, 2, Nxy + 3, Nxy + 4};
+            double w[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { w[0][u] = WL[sc[u]]; w[1][u] = WL[nbx + sc[u]]; w[2][u] = WR[sc[u]]; w[3][u] = WR[nbx + sc[u]]; }
+#pragma unroll
+            for (int q = 0; q < NQS; q++) {
+                const double c00 = inL ? dvL[q][0] : 0.0, c01 = inL ? dvL[q][1] : 0.0, c10 = inL ? daL[q][0] : 0.0, c11 = inL ? daL[q][1] : 0.0;
+                const double c20 = inR ? dvR[q][0] : 0.0, c21 = inR ? dvR[q][1] : 0.0, c30 = inR ? daR[q][0] : 0.0, c31 = inR ? daR[q][1] : 0.0;
+                double a0[4], a1[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    a0[u] = (w[0][u] * c00 + w[1][u] * c10) + (w[2][u] * c20 + w[3][u] * c30);
+                    a1[u] = (w[0][u] * c01 + w[1][u] * c11) + (w[2][u] * c21 + w[3][u] * c31);
+                }
+                if (!inL) { a0[0] += dvL[q][0]; a1[0] += dvL[q][1]; a0[1] += daL[q][0]; a1[1] += daL[q][1]; }      // an end knot's V, A are beta columns themselves
+                if (!inR) { a0[2] += dvR[q][0]; a1[2] += dvR[q][1]; a0[3] += daR[q][0]; a1[3] += daR[q][1]; }
+                double headtail_x = 0.0;
+                headtail_x += a0[0] * hd[2] + a1[0] * hd[3];
+                headtail_x += 2.0 * Tx * (a0[1] * hd[4] + a1[1] * hd[5]);
+                headtail_x += a0[2] * hd[8] + a1[2] * hd[9];
+                headtail_x += 2.0 * Tx * (a0[3] * hd[10] + a1[3] * hd[11]);
+                htx[q] = headtail_x;
+            }
+        }
+        // ---- yaw blocks
+        const bool yL = m >= 1, yR = m + 1 <= Nyaw - 1;
+        const auto VL = UPH_AS_GLOBAL(Wr_yaw + (size_t)(yL ? 2 * (m - 1) : 0) * nby);
+        const auto VR = UPH_AS_GLOBAL(Wr_yaw + (size_t)(yR ? 2 * m : 0) * nby);
+        const int qL = knotCol(m, Nyaw), qR = knotCol(m + 1, Nyaw);
+        for (int c0 = 3; c0 < Nyaw + 2; c0 += 8) {
+            double w[4][8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int cc = c0 + u < Nyaw + 2 ? c0 + u : Nyaw + 1;
+                w[0][u] = VL[cc]; w[1][u] = VL[nby + cc]; w[2][u] = VR[cc]; w[3][u] = VR[nby + cc];
+            }
+#pragma unroll
+            for (int q = 0; q < NQS; q++) {
+                const double y0_ = yL ? yvL[q] : 0.0, y1_ = yL ? yaL[q] : 0.0, y2_ = yR ? yvR[q] : 0.0, y3_ = yR ? yaR[q] : 0.0;
+                double mq = mx[q];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int col = c0 + u;
+                    double a0 = (w[0][u] * y0_ + w[1][u] * y1_) + (w[2][u] * y2_ + w[3][u] * y3_);
+                    if (col == qL) a0 += ypL[q];
+                    if (col == qR) a0 += ypR[q];
+                    if (col < Nyaw + 2) mq = dmax(mq, fabs(a0));
+                }
+                mx[q] = mq;
+            }
+        }
+        {
+            const int sc[4] = {1, 2, Nyaw + 3, Nyaw + 4};
+            double w[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { w[0][u] = VL[sc[u]]; w[1][u] = VL[nby + sc[u]]; w[2][u] = VR[sc[u]]; w[3][u] = VR[nby + sc[u]]; }
+#pragma unroll
+            for (int q = 0; q < NQS; q++) {
+                const double y0_ = yL ? yvL[q] : 0.0, y1_ = yL ? yaL[q] : 0.0, y2_ = yR ? yvR[q] : 0.0, y3_ = yR ? yaR[q] : 0.0;
+                double a0[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) a0[u] = (w[0][u] * y0_ + w[1][u] * y1_) + (w[2][u] * y2_ + w[3][u] * y3_);
+                if (!yL) { a0[0] += yvL[q]; a0[1] += yaL[q]; }
+                if (!yR) { a0[2] += yvR[q]; a0[3] += yaR[q]; }
+                double headtail_y = 0.0;
+                headtail_y += a0[0] * hd[13];
+                headtail_y += 2.0 * Ty * a0[1] * hd[14];
+                headtail_y += a0[2] * hd[16];
+                headtail_y += 2.0 * Ty * a0[3] * hd[17];
+                hty[q] = headtail_y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQS; q++) {
+            const double gTau = ((sumx[q] + htx[q]) / Nxy + (sumy[q] + hty[q]) / Nyaw) * dTau;                      // :642-644
+            scl[(Q0 + q) * S + s] = 1.0 / dmax(1.0, dmax(mx[q], fabs(gTau)));                                                // :658-659
+        }
     }
 
     // ------------------------------------------------------------------ line search (lbfgs.hpp:276-389)
