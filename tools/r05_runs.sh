@@ -149,6 +149,7 @@ done 2>&1 | tee $OUT/ab.txt
 TAG=${2:-r05f}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 python __graft_entry__.py smoke 2>&1 | tail -2 | tee $OUT/smoke.txt
+timeout 600 python tools/soak.py 2>&1 | tail -4 | tee $OUT/soak.txt
 timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
 tail -4 $OUT/gpu_tests.txt | cut -c1-300
 bash tools/profile.sh $TAG 2>&1 | tail -40 | cut -c1-300

@@ -11,6 +11,16 @@ mh = U.UnevenMap(); mh.build(scenes.make_hill_cloud())
 nx, ny = int(mh.voxel_num[0]), int(mh.voxel_num[1])
 QS, QG = scenes.random_queries(6000, seed0=9000, occ_r2=mh.occ_r2_buffer, grid=(nx, ny, mh.xy_resolution, mh.map_origin[0], mh.map_origin[1]))
 ka = U.KinoAstar(mh, slots=1024)
+# automatic workspaces (slots = 0, what plan() of the adapters uses): allocated for the batch that arrives, grown for a larger one, same results
+ka_auto = U.KinoAstar(mh)
+grown = []
+for nq in (1, 300, 5000):
+    ra = ka_auto.plan_batch(QS[:nq], QG[:nq], path_cap=256)
+    grown.append(ka_auto.L.uph_kino_slots(ka_auto.h))
+    rb = ka.plan_batch(QS[:nq], QG[:nq], path_cap=256)
+    assert all(a["status"] == b["status"] and a["iter_num"] == b["iter_num"] and np.array_equal(a["path"], b["path"]) for a, b in zip(ra, rb)), nq
+print("automatic search workspaces after batches of 1 / 300 / 5000 queries:", grown)
+assert grown[0] == 16 and grown[1] == 300 and grown[2] >= 4096 and grown[2] <= 5000, grown
 n_found = n_q = 0
 free0 = torch.cuda.mem_get_info()[0]
 rng = np.random.default_rng(0)
