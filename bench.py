@@ -314,6 +314,7 @@ def main():
     sst = single.stats()
     single_ms = sst["kernel_ms"] + sst["prepare_ms"]
     single_ms_per_iter = sst["kernel_ms"] / max(1, sst["lbfgs_iters"])
+    single_iters = sst["lbfgs_iters"]
     del single
     extras = {}
     if rank == 0 and not args.no_extras and not km2:
@@ -563,7 +564,8 @@ def main():
                        "rccl_world": dist.get_world_size() if distributed else 1, "parallelism": ("dp%d" % world) + (" (grid tiled by x-slab owner + 20 m halo)" if km2 and m.tile is not None else "")},
             "per_rank_ms_per_step": per_rank_ms,
             "ms_per_lbfgs_iter": single_ms_per_iter,       # single hill trajectory alone on the GPU (configs[1]): solve kernel ms / its L-BFGS iterations
-            "single_traj_ms": single_ms, "batch_lbfgs_iters_per_s": iters / dt,
+            "single_traj_ms": single_ms, "single_traj_lbfgs_iters": single_iters,      # (the solve is chaotic: a rounding-level change of the arithmetic moves this ONE problem's iteration count -- 216 / 253 in round 5 -- read ms_per_lbfgs_iter for the kernel)
+            "batch_lbfgs_iters_per_s": iters / dt,
             "lbfgs_iters_per_traj": iters / K / args.batch, "evals_per_traj": evals / K / args.batch,
             "scaling_kernel_ms": float(np.mean(prepare_ms)),
             "converged_frac": float((rets == 0).mean()), "map_build_s": map_build_s, "map_kernel_ms": map_stats["kernel_ms"],

@@ -186,4 +186,26 @@ except Exception as e:
 PY
 done 2>&1 | tee $OUT/ab.txt
 ;;
+9)
+# piece-aligned sample chunks (results move at rounding level: no bit identity with round 4 any more): A/B against the plain chunks (noalign), the tests that
+# compare with the oracle, the drift / bucket statistics at N = 4096 again
+OUT=gpurun_out/r05m; mkdir -p $OUT
+for v in noalign default noalign default; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu --no-extras > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  python - $OUT/bench_$v.json $v <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+    print('%-10s value %.0f traj/s  step %.1f ms  launch %.1f ms  frac %.3f  converged %.3f  evals/traj %.2f  single traj %.2f ms' % (sys.argv[2], r['value'], r['ms_per_step'], r['roofline']['avg_launch_ms'], r['roofline']['frac'], r['converged_frac'], r['evals_per_traj'], r['single_traj_ms']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e, open(sys.argv[1].replace('.json', '.err')).read()[-400:])
+PY
+done 2>&1 | tee $OUT/ab.txt
+unset UNEVENHIP_LIB
+timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -6 $OUT/gpu_tests.txt | cut -c1-300
+UPH_PB_ONLY_YAML=1 UPH_PB_THREADS=96 timeout 900 python tools/parity_buckets.py 4096 $OUT/parity_buckets_hill_4096.json hill > $OUT/parity_buckets_hill_4096.txt 2>&1
+tail -9 $OUT/parity_buckets_hill_4096.txt | cut -c1-700
+;;
 esac

@@ -66,6 +66,7 @@ struct Solver {
     const BatchDev& bd;
     const TrajDesc& td;
     int Nxy, Nyaw, n, S, K, mem, CH, CHP, recd;
+    int CHS;             // samples per chunk of the sample / scatter loop (<= CH, the record slots): see the constructor
     // workgroup-shared arrays (LDS)
     int* rtag;
     double *x, *xp, *g, *gp, *d, *cxy, *cyaw, *Gxy, *Gyaw, *gamxy, *gamyaw, *bt, *rec, *wtab, *ttab, *pf, *hd;
@@ -104,6 +105,18 @@ struct Solver {
         Nxy = td.Nxy; Nyaw = td.Nyaw; n = td.n; S = td.S; K = P.int_K; mem = P.mem_size;
         inv_k1 = 1.0f / (float)(K + 1);
         CH = wg.size(); CHP = CH + 1; recd = REC_FIELDS * CHP + (CH + 1) / 2;      // (ldsDoubles may have reserved more; only the size matters here)
+        // Chunks of whole pieces where that costs no extra chunk.  A chunk of CH = 128 consecutive samples overlaps 8 or 9 pieces of K + 1 = 17 samples; with 9
+        // the xy scatter needs a second 16-column MFMA tile for ONE piece -- a full 13-step pass on the wave that also sums the yaw blocks, while the other
+        // wave waits.  floor(CH / (K + 1)) whole pieces per chunk (7 x 17 = 119 samples) never need it, and for most piece counts that is the same number
+        // of chunks (e.g. 39 pieces: 6 either way; 22 pieces: 4 against 3 -- those keep the plain chunks, a chunk's sample pass costs the same however
+        // full it is).  Which samples share a chunk decides the association of the per-chunk sums: results move at rounding level with this choice.
+        CHS = CH;
+#if !defined(UPH_ALIGNED_CHUNKS) || UPH_ALIGNED_CHUNKS
+        {
+            const int ppc = CH / (K + 1);
+            if (ppc >= 1 && (Nxy + ppc - 1) / ppc == (S + CH - 1) / CH) CHS = ppc * (K + 1);
+        }
+#endif
         // field stride CH + 1 doubles: with stride CH (1 KB) the field rows of a piece start in the same LDS bank and the
         // scatter's per-(piece, field) lanes conflict
         double* q = lds;
@@ -836,8 +849,8 @@ struct Solver {
         const double jerk_cost = wg.bcast(P.use_scaling ? js[0] * scale_fx * scale_trick_jerk : js[0] * scale_fx);
         evalConsts();
         double sm[3] = {0.0, 0.0, 0.0};
-        for (int s0 = 0; s0 < S; s0 += CH) {
-            const int cnt = S - s0 < CH ? S - s0 : CH;
+        for (int s0 = 0; s0 < S; s0 += CHS) {
+            const int cnt = S - s0 < CHS ? S - s0 : CHS;
             double part[3] = {0.0, 0.0, 0.0};
             t0 = wg.clock();
             if (UPH_PHASE_MASK & 2) wg.template sum<3>(cnt, part, [&](int t, double* acc) { sampleEval<false, SR>(s0 + t, t, acc); });
@@ -870,8 +883,8 @@ struct Solver {
         double js[3];
         expand(x0, 1.0, js);
         double sm[3] = {0.0, 0.0, 0.0};
-        for (int s0 = 0; s0 < S; s0 += CH) {
-            const int cnt = S - s0 < CH ? S - s0 : CH;
+        for (int s0 = 0; s0 < S; s0 += CHS) {
+            const int cnt = S - s0 < CHS ? S - s0 : CHS;
             double part[3];
             wg.template sum<3>(cnt, part, [&](int t, double* acc) { sampleObjective(s0 + t, t, acc); });
             sm[0] += part[0]; sm[1] += part[1]; sm[2] += part[2];
