@@ -47,6 +47,28 @@ struct HostWG {
     }
     // lbfgs.hpp:687-710, plain loops
     double bcast(double v) const { return v; }
+    // the reduction split over several regions (DevWG::accBegin / accChunk / accEnd): per-lane partials kept across the chunks, one butterfly at the end
+    double pacc_[NT][8];
+    template <int M>
+    void accBegin() { for (int t = 0; t < NT; t++) for (int m = 0; m < M; m++) pacc_[t][m] = 0.0; }
+    template <int M, class F>
+    void accChunk(int n, F f) { const int L = g_lanes; for (int t = 0; t < L; t++) for (int i = t; i < n; i += L) f(i, pacc_[t]); }
+    template <int M>
+    void accEnd(double* out) {
+        for (int m = 0; m < M; m++) {
+            double total = 0.0;
+            for (int w = 0; w < g_lanes / 64; w++) {
+                double a[64], b[64];
+                for (int l = 0; l < 64; l++) a[l] = pacc_[w * 64 + l][m];
+                for (int off = 32; off >= 1; off >>= 1) {
+                    for (int l = 0; l < 64; l++) b[l] = a[l] + a[l ^ off];
+                    std::memcpy(a, b, sizeof(a));
+                }
+                total = (w == 0) ? a[0] : total + a[0];
+            }
+            out[m] = total;
+        }
+    }
     template <int MS, int MM, class F>
     void sumMax(int n, double* outS, double* outM, F f) {
         static double part[NT][MS], pm[NT][MM];

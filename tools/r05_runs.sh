@@ -208,4 +208,22 @@ tail -6 $OUT/gpu_tests.txt | cut -c1-300
 UPH_PB_ONLY_YAML=1 UPH_PB_THREADS=96 timeout 900 python tools/parity_buckets.py 4096 $OUT/parity_buckets_hill_4096.json hill > $OUT/parity_buckets_hill_4096.txt 2>&1
 tail -9 $OUT/parity_buckets_hill_4096.txt | cut -c1-700
 ;;
+10)
+# generic A/B of the in-tree library against one variant build: bash tools/r05_runs.sh 10 <variant> [tag]; then the oracle-comparing tests
+V=${2:-prev}; OUT=gpurun_out/${3:-r05ab}; mkdir -p $OUT
+for v in $V default $V default; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu --no-extras > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  python - $OUT/bench_$v.json $v <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+    print('%-10s value %.0f traj/s  step %.1f ms  launch %.1f ms  frac %.3f  converged %.3f  evals/traj %.2f  single traj %.2f ms (%s iterations, %.4f ms each)' % (sys.argv[2], r['value'], r['ms_per_step'], r['roofline']['avg_launch_ms'], r['roofline']['frac'], r['converged_frac'], r['evals_per_traj'], r['single_traj_ms'], r.get('single_traj_lbfgs_iters'), r['ms_per_lbfgs_iter']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e, open(sys.argv[1].replace('.json', '.err')).read()[-400:])
+PY
+done 2>&1 | tee $OUT/ab.txt
+unset UNEVENHIP_LIB
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_forced.py tests/test_gpu_edge.py tests/test_gpu_lanes.py tests/test_gpu_buckets.py tests/test_gpu_km2.py tests/test_gpu_fullsize.py -m gpu -q 2>&1 | tail -4 | cut -c1-300
+;;
 esac

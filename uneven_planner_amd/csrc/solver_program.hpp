@@ -848,17 +848,18 @@ struct Solver {
         last_jerk = js[0];
         const double jerk_cost = wg.bcast(P.use_scaling ? js[0] * scale_fx * scale_trick_jerk : js[0] * scale_fx);
         evalConsts();
+        // (cost, dT_xy, dT_yaw) of the samples: every lane keeps its partials across the chunks, ONE block reduction after the last chunk (wg.accEnd)
         double sm[3] = {0.0, 0.0, 0.0};
+        wg.template accBegin<3>();
         for (int s0 = 0; s0 < S; s0 += CHS) {
             const int cnt = S - s0 < CHS ? S - s0 : CHS;
-            double part[3] = {0.0, 0.0, 0.0};
             t0 = wg.clock();
-            if (UPH_PHASE_MASK & 2) wg.template sum<3>(cnt, part, [&](int t, double* acc) { sampleEval<false, SR>(s0 + t, t, acc); });
+            if (UPH_PHASE_MASK & 2) wg.template accChunk<3>(cnt, [&](int t, double* acc) { sampleEval<false, SR>(s0 + t, t, acc); });
             t1 = wg.clock(); cyc[1] += t1 - t0;
-            sm[0] += part[0]; sm[1] += part[1]; sm[2] += part[2];
             if (UPH_PHASE_MASK & 4) scatterChunk(s0, cnt);
             cyc[2] += wg.clock() - t1;
         }
+        wg.template accEnd<3>(sm);
         t1 = wg.clock();
         double chx = 0.0, chy = 0.0, gdw = 0.0;
         if (UPH_PHASE_MASK & 8) adjoint(chx, chy, gout, &gdw);

@@ -231,6 +231,40 @@ struct DevWG {
             out[m] = uni(t);
         }
     }
+    // The same reduction split over several parallel regions: accBegin zeroes the lane's partials, every accChunk adds its region's terms to them (and ends
+    // with the barrier the region needs anyway), accEnd is the wave sum / LDS exchange -- ONCE.  The sample loop of an objective evaluation runs 3 to 6
+    // chunks; reducing (cost, dT_xy, dT_yaw) after each of them cost three wave sums and an LDS round trip per chunk that nothing was waiting for.
+    double pacc[MAXM];
+    template <int M>
+    __device__ __forceinline__ void accBegin() {
+#pragma unroll
+        for (int m = 0; m < M; m++) pacc[m] = 0.0;
+    }
+    template <int M, class F>
+    __device__ __forceinline__ void accChunk(int n, F f) {
+        for (int i = ftid(); i < n; i += NT) f(i, pacc);
+        bar(0);
+    }
+    template <int M>
+    __device__ __forceinline__ void accEnd(double* out) {
+        double acc[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) acc[m] = waveSum(pacc[m]);
+        double* r = red + par * (NW * MAXM);
+        par ^= 1;
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < M; m++) r[wave * MAXM + m] = acc[m];
+        }
+        bar(0);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            double t = r[m];
+#pragma unroll
+            for (int w = 1; w < NW; w++) t += r[w * MAXM + m];
+            out[m] = uni(t);
+        }
+    }
     // MS sums and MM maxima of non-negative values in one pass and one barrier (the L-BFGS bookkeeping pass)
     template <int MS, int MM, class F>
     __device__ __forceinline__ void sumMax(int n, double* outS, double* outM, F f) {
