@@ -226,4 +226,21 @@ done 2>&1 | tee $OUT/ab.txt
 unset UNEVENHIP_LIB
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_forced.py tests/test_gpu_edge.py tests/test_gpu_lanes.py tests/test_gpu_buckets.py tests/test_gpu_km2.py tests/test_gpu_fullsize.py -m gpu -q 2>&1 | tail -4 | cut -c1-300
 ;;
+11)
+# final record of the round: smoke, soak, whole GPU tier, tools/profile.sh, the bench lines with the fresh counter pass in place, drift / bucket tables at N = 4096
+TAG=${2:-r05r}
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+python __graft_entry__.py smoke 2>&1 | tail -1 | tee $OUT/smoke.txt
+timeout 600 python tools/soak.py 2>&1 | tail -4 | tee $OUT/soak.txt
+timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -3 $OUT/gpu_tests.txt | cut -c1-300
+bash tools/profile.sh $TAG 2>&1 | tail -12 | cut -c1-200
+cp gpurun_out/prof_$TAG/pmc_traffic.json profiles/pmc_traffic.json
+python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?"
+timeout 600 python bench.py --workload km2 --steps 3 --warmup 1 > $OUT/bench_km2.json 2> $OUT/bench_km2.err; echo "km2 rc $?"
+UPH_PB_ONLY_YAML=1 UPH_PB_THREADS=96 timeout 900 python tools/parity_buckets.py 4096 $OUT/parity_buckets_hill_4096.json hill > $OUT/parity_buckets_hill_4096.txt 2>&1
+tail -9 $OUT/parity_buckets_hill_4096.txt | cut -c1-700
+UPH_PB_THREADS=96 timeout 900 python tools/parity_buckets.py 4096 $OUT/parity_buckets_desert_4096.json desert > $OUT/parity_buckets_desert_4096.txt 2>&1
+tail -9 $OUT/parity_buckets_desert_4096.txt | cut -c1-700
+;;
 esac
