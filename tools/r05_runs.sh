@@ -243,4 +243,47 @@ tail -9 $OUT/parity_buckets_hill_4096.txt | cut -c1-700
 UPH_PB_THREADS=96 timeout 900 python tools/parity_buckets.py 4096 $OUT/parity_buckets_desert_4096.json desert > $OUT/parity_buckets_desert_4096.txt 2>&1
 tail -9 $OUT/parity_buckets_desert_4096.txt | cut -c1-700
 ;;
+12)
+# the gather without its dead register pair (loadCell<.., WITH_Z = false>): bit identity against the r05r library, A/B of the solve launch (+ the variant that
+# requests the next chunk's gather before the scatter, -DUPH_GATHER_AHEAD=1), one full bench line of the new build for the penalty kernel
+OUT=gpurun_out/${2:-r05s}; mkdir -p $OUT
+python tools/cmp_variant.py $OUT/x_default.npy 2>&1 | tail -1
+UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_r05r.so python tools/cmp_variant.py $OUT/x_r05r.npy 2>&1 | tail -1
+UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_ahead.so python tools/cmp_variant.py $OUT/x_ahead.npy 2>&1 | tail -1
+python -c "
+import numpy as np
+a, b, c = np.load('$OUT/x_default.npy'), np.load('$OUT/x_r05r.npy'), np.load('$OUT/x_ahead.npy')
+print('hill, 64 solves: this build vs the r05r library bit-identical', np.array_equal(a, b), '; gather-ahead variant bit-identical', np.array_equal(a, c), 'max diff', np.abs(a - c).max())" | tee $OUT/bit_identity.txt
+for v in r05r default ahead r05r default ahead; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu --no-extras > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  python - $OUT/bench_$v.json $v <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+    print('%-10s value %.0f traj/s  step %.1f ms  launch %.1f ms  frac %.3f  converged %.3f  evals/traj %.2f  single traj %.2f ms (%s iterations, %.4f ms each)' % (sys.argv[2], r['value'], r['ms_per_step'], r['roofline']['avg_launch_ms'], r['roofline']['frac'], r['converged_frac'], r['evals_per_traj'], r['single_traj_ms'], r.get('single_traj_lbfgs_iters'), r['ms_per_lbfgs_iter']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e, open(sys.argv[1].replace('.json', '.err')).read()[-400:])
+PY
+done 2>&1 | tee $OUT/ab.txt
+unset UNEVENHIP_LIB
+timeout 400 python bench.py --steps 4 --warmup 1 --no-cpu > $OUT/bench_full.json 2> $OUT/bench_full.err
+python - $OUT/bench_full.json <<'PY' | tee -a $OUT/ab.txt
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+print('new build, full line: value %.0f  launch %.1f ms  frac %.3f  penalty kernel %.3f / %.3f  B8192 %.0f  B4096 %.0f  B256 %.0f  astar %.0f' % (r['value'], r['roofline']['avg_launch_ms'], r['roofline']['frac'], r['roofline']['penalty_kernel']['frac'], r['roofline']['penalty_kernel']['frac_hill_trajectory_x256'], r['traj_opts_per_s_B8192'], r['traj_opts_per_s_B4096'], r['traj_opts_per_s_B256'], r['traj_opts_per_s_astar_seeded']))
+PY
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_km2.py tests/test_gpu_map.py -m gpu -q 2>&1 | tail -3 | cut -c1-300
+;;
+13)
+# generic: bit identity of the in-tree library against one variant build (64 hill solves), then case 10's A/B and tests: bash tools/r05_runs.sh 13 <variant> [tag]
+V=${2:-prev}; OUT=gpurun_out/${3:-r05ab}; mkdir -p $OUT
+python tools/cmp_variant.py $OUT/x_default.npy 2>&1 | tail -1
+UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$V.so python tools/cmp_variant.py $OUT/x_$V.npy 2>&1 | tail -1
+python -c "
+import numpy as np
+a, b = np.load('$OUT/x_default.npy'), np.load('$OUT/x_$V.npy')
+print('hill, 64 solves: this build vs the $V library bit-identical', np.array_equal(a, b), 'max diff', np.abs(a - b).max())" | tee $OUT/bit_identity.txt
+bash tools/r05_runs.sh 10 $V ${3:-r05ab}
+;;
 esac

@@ -76,26 +76,37 @@ UPH_HD void locate(const GridDev& g, R x, R y, R yaw, CornersT<R>& c) {
 // One cell of the grid: {z, sigma, zb.x, zb.y} in the reference's RXS2 order (uneven_map.h:36-64, 427-435), stored either as four
 // doubles (32 bytes, two 16-byte loads; bit-faithful to the reference's map_buffer) or -- GridDev::cells32, BASELINE.json configs[4] --
 // as four floats (16 bytes, one load) widened to double on load: the arithmetic is fp64 either way.
-template <bool F32, class R>
+// WITH_Z = false requests sigma and zb only -- an 8-byte and a 16-byte load instead of two 16-byte loads.  Not for the eight bytes: a register pair that a
+// load fills and nobody reads is free for reuse as far as the compiler is concerned, and its next writer has to wait for the load to land first
+// (s_waitcnt before the overwrite).  In the sample code that was the address temporary of the NEXT cell: the first cell's round trip to the grid ran to
+// completion before the other fifteen loads of the gather were even issued.
+template <bool F32, class R, bool WITH_Z = true>
 UPH_HD void loadCell(const GridDev& g, uint32_t idx, R f[4]) {           // f = {sigma, zb.x, zb.y, z}
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef double dbl2_t __attribute__((ext_vector_type(2)));
     typedef float flt4_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) dbl2_t* cellp;
     typedef const __attribute__((address_space(1))) flt4_t* cellp32;
+    typedef const __attribute__((address_space(1))) double* wordp;
 #else
     struct dbl2_t { double x, y; };
     struct flt4_t { float x, y, z, w; };
     typedef const dbl2_t* cellp;
     typedef const flt4_t* cellp32;
+    typedef const double* wordp;
 #endif
     if (F32) {
         const flt4_t v = ((cellp32)g.cells32)[idx];
         f[3] = toReal<R>(v.x); f[0] = toReal<R>(v.y); f[1] = toReal<R>(v.z); f[2] = toReal<R>(v.w);
-    } else {
+    } else if (WITH_Z) {
         const cellp p = (cellp)(g.cells + 4 * (size_t)idx);
         const dbl2_t lo = p[0], hi = p[1];                  // (z, sigma), (zb.x, zb.y)
         f[3] = lo.x; f[0] = lo.y; f[1] = hi.x; f[2] = hi.y;
+    } else {
+        const double* p = g.cells + 4 * (size_t)idx;
+        const double sg = ((wordp)p)[1];
+        const dbl2_t hi = ((cellp)p)[1];
+        f[3] = R(0.0); f[0] = sg; f[1] = hi.x; f[2] = hi.y;
     }
 }
 
@@ -103,19 +114,14 @@ UPH_HD void loadCell(const GridDev& g, uint32_t idx, R f[4]) {           // f = 
 // three at a located point: the operations and their order of uneven_map.h:297-311 (values alone: :192-198, the same expressions).
 // One yaw slice at a time -- the bilinear values and the x / y partial sums of a slice need only that slice's four cells, the two
 // slices meet in the last lerp -- so at most four cells are live at once (eight corners = 16 x 16-byte loads in the fp64 form, 8 in fp32).
-template <bool F32, bool GRAD, bool WITH_Z, class R>
-UPH_HD void interpCells(const GridDev& g, const CornersT<R>& c, R val[4], R grd[3][3]) {
+template <bool GRAD, bool WITH_Z, class R, class CELLS>
+UPH_HD void interpCellsWith(const GridDev& g, R dx, R dy, R dw, CELLS cells, R val[4], R grd[3][3]) {      // cells(w, f): the four cells f[x][y][field] of yaw slice w
     constexpr int NF = WITH_Z ? 4 : 3;
-    const R dx = c.dx, dy = c.dy, dw = c.dyaw;
     R v0[NF], v1[NF], gy0[3], gy1[3], gx[3];
 #pragma unroll
     for (int w = 0; w < 2; w++) {
-        const int wi = w == 0 ? c.w0 : c.w1;
         R f[2][2][4];                                  // (requesting all eight cells before the first use was measured: no gain under load, -0.7 %)
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) loadCell<F32, R>(g, c.a[a][b] + (uint32_t)wi, f[a][b]);
+        cells(w, f);
 #pragma unroll
         for (int k = 0; k < NF; k++) {
             const R vy0 = f[0][0][k] * (1 - dx) + f[1][0][k] * dx;       // v00 / v01 of uneven_map.h:297-300
@@ -138,6 +144,16 @@ UPH_HD void interpCells(const GridDev& g, const CornersT<R>& c, R val[4], R grd[
             grd[k][0] = gx[k] * g.xy_inv;
         }
     }
+}
+template <bool F32, bool GRAD, bool WITH_Z, class R>
+UPH_HD void interpCells(const GridDev& g, const CornersT<R>& c, R val[4], R grd[3][3]) {
+    interpCellsWith<GRAD, WITH_Z, R>(g, c.dx, c.dy, c.dyaw, [&](int w, R f[2][2][4]) {
+        const int wi = w == 0 ? c.w0 : c.w1;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) loadCell<F32, R, WITH_Z>(g, c.a[a][b] + (uint32_t)wi, f[a][b]);
+    }, val, grd);
 }
 
 // Base quantities for the fused penalty kernel: interpolated (sigma, zb.x, zb.y) and their gradients w.r.t. (x, y, yaw).
