@@ -286,4 +286,30 @@ a, b = np.load('$OUT/x_default.npy'), np.load('$OUT/x_$V.npy')
 print('hill, 64 solves: this build vs the $V library bit-identical', np.array_equal(a, b), 'max diff', np.abs(a - b).max())" | tee $OUT/bit_identity.txt
 bash tools/r05_runs.sh 10 $V ${3:-r05ab}
 ;;
+14)
+# A/B of one or more variant builds against the in-tree library, nothing else: bash tools/r05_runs.sh 14 <tag> <variant> [<variant> ...]; then the per-evaluation parity
+# tests on the first variant
+OUT=gpurun_out/${2:-r05ab}; mkdir -p $OUT; shift 2
+python tools/cmp_variant.py $OUT/x_default.npy 2>&1 | tail -1
+for v in "$@"; do
+  UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so python tools/cmp_variant.py $OUT/x_$v.npy 2>&1 | tail -1
+  python -c "
+import numpy as np
+a, b = np.load('$OUT/x_default.npy'), np.load('$OUT/x_$v.npy')
+print('hill, 64 solves: $v vs the in-tree library bit-identical', np.array_equal(a, b), 'max diff', np.abs(a - b).max())" | tee -a $OUT/bit_identity.txt
+done
+for v in default "$@" default "$@"; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu --no-extras > $OUT/bench_$v.json 2> $OUT/bench_$v.err
+  python - $OUT/bench_$v.json $v <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1])
+    print('%-10s value %.0f traj/s  step %.1f ms  launch %.1f ms  frac %.3f  converged %.3f  evals/traj %.2f  single traj %.2f ms (%s iterations, %.4f ms each)' % (sys.argv[2], r['value'], r['ms_per_step'], r['roofline']['avg_launch_ms'], r['roofline']['frac'], r['converged_frac'], r['evals_per_traj'], r['single_traj_ms'], r.get('single_traj_lbfgs_iters'), r['ms_per_lbfgs_iter']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e, open(sys.argv[1].replace('.json', '.err')).read()[-400:])
+PY
+done 2>&1 | tee $OUT/ab.txt
+UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$1.so timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge.py -m gpu -q 2>&1 | tail -2 | cut -c1-300
+;;
 esac
