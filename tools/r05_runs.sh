@@ -312,4 +312,12 @@ PY
 done 2>&1 | tee $OUT/ab.txt
 UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$1.so timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge.py -m gpu -q 2>&1 | tail -2 | cut -c1-300
 ;;
+15)
+# drift statistics on larger samples (final build): hill N = 16384, volcano N = 4096
+OUT=gpurun_out/${2:-r05w}; mkdir -p $OUT
+UPH_PB_ONLY_YAML=1 UPH_PB_THREADS=192 timeout 1200 python tools/parity_buckets.py 16384 $OUT/parity_buckets_hill_16384.json hill > $OUT/parity_buckets_hill_16384.txt 2>&1
+tail -9 $OUT/parity_buckets_hill_16384.txt | cut -c1-700
+UPH_PB_THREADS=192 timeout 900 python tools/parity_buckets.py 4096 $OUT/parity_buckets_vocano_4096.json vocano > $OUT/parity_buckets_vocano_4096.txt 2>&1
+tail -9 $OUT/parity_buckets_vocano_4096.txt | cut -c1-700
+;;
 esac
