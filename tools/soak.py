@@ -25,7 +25,7 @@ n_found = n_q = 0
 free0 = torch.cuda.mem_get_info()[0]
 rng = np.random.default_rng(0)
 t0 = time.time()
-for it in range(40):
+for it in range(int(os.environ.get("UPH_SOAK_ITERS", "40"))):      # UPH_SOAK_ITERS=1500: a three-minute soak
     B = int(rng.choice([1, 2, 3, 64, 200, 256, 257, 511, 512, 1000, 2303, 2304, 3000]))
     idx = rng.choice(3000, B, replace=False)
     opt.set_rho(1.0)
@@ -42,7 +42,7 @@ for it in range(40):
     if it == 10:
         free1 = torch.cuda.mem_get_info()[0]
 free2 = torch.cuda.mem_get_info()[0]
-print("40 mixed batches in %.1f s; free memory start %.0f MB, after 10 %.0f MB, end %.0f MB" % (time.time() - t0, free0 / 2**20, free1 / 2**20, free2 / 2**20))
+print("%s mixed batches in %.1f s; free memory start %.0f MB, after 10 %.0f MB, end %.0f MB" % (os.environ.get("UPH_SOAK_ITERS", "40"), time.time() - t0, free0 / 2**20, free1 / 2**20, free2 / 2**20))
 assert free1 - free2 < 64 * 2**20, "device memory keeps growing"
 print("front end: %d of %d queries found a path" % (n_found, n_q))
 assert n_found > 0.9 * n_q
