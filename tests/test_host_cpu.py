@@ -260,3 +260,41 @@ def test_tile_rows_and_owner_routing_cover_every_problem():
                 xs = np.concatenate([p["init_xy"][0, :1], p["end_xy"][0, :1], p["inner_xy"][0]])
                 assert owner_of(p, nx, world, res, ox) == rank
                 assert (xs.min() >= lo_m + 2.0 or x0 == 0) and (xs.max() <= hi_m - 2.0 or x1 == nx)      # UPH_TILE_MARGIN of the upload check
+
+
+def test_isa_scan_flags_a_load_with_a_dead_destination(tmp_path):
+    """tools/isa_waw_waits.py on two synthetic kernels: the round-5 terrain gather as it was (a 16-byte load whose first register pair is never
+    read and is reused as the next address temporary: the wait in front of the overwrite is reported) and as it is (an 8-byte and a 16-byte load,
+    every destination read: nothing to report)."""
+    import subprocess, sys
+    dead = """
+0000000000001000 <kernel_dead_pair>:
+	global_load_dwordx4 v[38:41], v[42:43], off                // 000000001000: DC5C8000
+	global_load_dwordx4 v[46:49], v[42:43], off offset:16      // 000000001008: DC5C8010
+	v_mov_b32_e32 v57, v133                                    // 000000001010: 7E720385
+	s_waitcnt vmcnt(1)                                         // 000000001014: BF8C0F71
+	v_lshlrev_b64 v[38:39], 5, v[56:57]                        // 000000001018: D28F0026
+	global_load_dwordx4 v[42:45], v[38:39], off                // 000000001020: DC5C8000
+	s_waitcnt vmcnt(0)                                         // 000000001028: BF8C0F70
+	v_add_f64 v[50:51], v[40:41], v[46:47]                     // 00000000102C: D2800032
+	s_endpgm                                                   // 000000001034: BF810000
+"""
+    clean = """
+0000000000002000 <kernel_clean>:
+	global_load_dwordx2 v[168:169], v[38:39], off offset:24    // 000000002000: DC548018
+	global_load_dwordx4 v[38:41], v[38:39], off offset:8       // 000000002008: DC5C8008
+	global_load_dwordx2 v[186:187], v[42:43], off offset:24    // 000000002010: DC548018
+	global_load_dwordx4 v[42:45], v[42:43], off offset:8       // 000000002018: DC5C8008
+	s_waitcnt vmcnt(2)                                         // 000000002020: BF8C0F72
+	v_add_f64 v[50:51], v[168:169], v[38:39]                   // 000000002024: D2800032
+	s_waitcnt vmcnt(0)                                         // 00000000202C: BF8C0F70
+	v_add_f64 v[52:53], v[186:187], v[42:43]                   // 000000002030: D2800034
+	s_endpgm                                                   // 000000002038: BF810000
+"""
+    f = tmp_path / "k.s"
+    f.write_text("\nx.co:\tfile format elf64-amdgpu\n\nDisassembly of section .text:\n" + dead + clean)
+    tool = os.path.join(os.path.dirname(__file__), "..", "tools", "isa_waw_waits.py")
+    out = subprocess.run([sys.executable, tool, str(f), "kernel_dead_pair", "vm"], capture_output=True, text=True, check=True).stdout
+    assert "WAW-suspect wait at 3" in out and "v_lshlrev_b64 v[38:39]" in out, out
+    out = subprocess.run([sys.executable, tool, str(f), "kernel_clean", "vm"], capture_output=True, text=True, check=True).stdout
+    assert "WAW-suspect" not in out, out
