@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <locale.h>
 #include <string>
 #include <vector>
 
@@ -17,6 +18,15 @@ namespace uph { void setError(const std::string& s); }      // unevenhip.hip (th
 using uph::setError;
 
 static const char BIN_MAGIC[8] = {'U', 'P', 'H', 'M', 'A', 'P', '0', '1'};
+
+// The numbers of a .map file are written and parsed in the "C" locale whatever the host process has selected with setlocale(): a decimal comma would
+// break the format on the way out and truncate every value at the point on the way in.  (The reference's ostream writes with the C++ global locale --
+// classic unless the host changes that too -- and parses with stold, i.e. with the C locale in force.)  Per thread (uselocale), restored on scope exit.
+struct CNumericLocale {
+    locale_t c, old;
+    CNumericLocale() : c(newlocale(LC_NUMERIC_MASK, "C", (locale_t)0)), old(c ? uselocale(c) : (locale_t)0) {}
+    ~CNumericLocale() { if (c) { uselocale(old); freelocale(c); } }
+};
 
 static bool dimsOk(const int32_t d[3]) { return d && d[0] > 0 && d[1] > 0 && d[2] > 0 && (int64_t)d[0] * d[1] * d[2] < ((int64_t)1 << 40); }
 
@@ -31,6 +41,7 @@ int uph_map_save_csv(const char* path, const double* rxs2, const int32_t dims3[3
     if (!f) { setError(std::string("uph_map_save_csv: cannot open ") + path + ": " + std::strerror(errno)); return UPH_ERR_INVALID; }
     std::vector<char> buf(1 << 20);
     std::setvbuf(f, buf.data(), _IOFBF, buf.size());
+    const CNumericLocale in_c;
     const double* c = rxs2;
     bool ok = true;
     for (int x = 0; x < dims3[0] && ok; x++)
@@ -58,6 +69,7 @@ int uph_map_load_csv(const char* path, const int32_t dims3[3], double* rxs2, dou
     std::memset(rxs2, 0, sizeof(double) * 4 * (size_t)ncell);
     if (c) for (int64_t i = 0; i < ncell; i++) c[i] = 1.0;
     int64_t used = 0;
+    const CNumericLocale in_c;
     char* line = nullptr;
     size_t cap = 0;
     ssize_t len;
