@@ -23,6 +23,7 @@
  *   uph_map_filter_cloud    <- pcl::CropBox + pcl::VoxelGrid as UnevenMap::init applies them  uneven_map.cpp:133-143
  *   uph_frontend_query      <- UnevenMap::getTerrainSig / isOccupancy / isOccupancyXY  uneven_map.h:389-396, 471-498 (batched)
  *   uph_eval_batch          <- innerCallback  alm_traj_opt.cpp:280-347 (one objective+gradient evaluation; test/bench hook)
+ *   uph_penalty_batch       <- ALMTrajOpt::calConstrainCostGrad  alm_traj_opt.cpp:663-991 (the penalty kernel alone; test/bench hook)
  *   uph_init_scaling_batch  <- ALMTrajOpt::initScaling  alm_traj_opt.cpp:349-661 (test hook)
  *   uph_report_batch        <- ALMTrajOpt::getMaxVxAxAyCurAttSig alm_traj_opt.h:170-229 + SE2Trajectory::getNonHolError
  *                              se2traj.hpp:551-561
@@ -52,6 +53,7 @@ typedef struct uph_kino uph_kino; /* front-end search context bound to one map: 
 #define UPH_ERR_HIP (-2)       /* a HIP runtime call failed (see uph_last_error) */
 #define UPH_ERR_NO_DEVICE (-3) /* no gfx950 device visible                        */
 #define UPH_ERR_LIMIT (-4)     /* problem exceeds a compiled limit (UPH_MAX_*)    */
+#define UPH_ERR_NO_CACHE (-5)  /* uph_map_load_cache only: neither cache file is readable -- build the map (uneven_map.cpp:166-167); any other code is a real failure */
 
 /* uph_result.ret_code beyond the reference's 0 / 1 / 2: */
 #define UPH_RET_STOPPED 3      /* test hook only: the ALM loop was stopped by uph_batch_alm_passes' pass cap                          */
@@ -242,7 +244,10 @@ int uph_map_load_bin(const char* path, const int32_t dims3[3], double* rxs2);
 /* the same against a device map: save = download the cells and write the CSV and / or the side-car (either path may be NULL); load =
  * constructMapInput: the side-car if bin_path names a readable one for this grid that is not older than the CSV (the CSV is the reference's own
  * cache and the source of truth: one regenerated later wins), else the CSV, then uph_map_set_cells (commit: c, occupancy).
- * source (may be NULL): 2 side-car, 1 CSV.  UPH_ERR_INVALID when no cache can be read: build the map then. */
+ * A named CSV that does not exist means NO cache even when a side-car lies next to it (the reference rebuilds whenever map_file is absent,
+ * uneven_map.cpp:166-167, 270-277); the side-car alone is used only with csv_path == NULL.
+ * source (may be NULL): 2 side-car, 1 CSV.  UPH_ERR_NO_CACHE when no cache can be read: build the map then (every other error code -- a tile
+ * map, a grid that does not fit host memory, a HIP failure -- is a failure, not a reason to rebuild and overwrite the cache). */
 int uph_map_save_cache(uph_map* m, const char* csv_path, const char* bin_path);
 int uph_map_load_cache(uph_map* m, const char* csv_path, const char* bin_path, int32_t* source);
 /* constructMap on the x-slab [x0, x1): crop box + 1 cm voxel filter, xy bucketing and plane fits all on the device (the host uploads the cloud).
@@ -402,6 +407,14 @@ int uph_batch_cycles(uph_ctx* c, long long* out);
  * one innerCallback evaluation at x (packed [sum n]); outputs f[B], grad (packed), and refreshes hx/gx/c on the device.
  * `repeat` >= 1 re-runs the same evaluation that many times inside one launch per trajectory (roofline measurement). */
 int uph_eval_batch(uph_ctx* c, const double* x_packed, double* f, double* grad_packed, int32_t repeat);
+/* A5 ALONE -- ALMTrajOpt::calConstrainCostGrad (back_end/src/alm_traj_opt.cpp:663-991) and nothing else of innerCallback: the coefficients and piece
+ * durations RESIDENT on the device (those of the last uph_eval_batch / solve of this batch), the resident duals, scales, rho and scale_fx in ->
+ * cost[B], gdCxy (packed [sum 12 Nxy]: per trajectory the reference's 6 Nxy x 2 block, row 6 i + k, row-major), gdCyaw (packed [sum 6 Nyaw]),
+ * gdT2[B][2] = (sum_i gdTxy(i), sum_i gdTyaw(i)) -- the pieces share one duration (alm_traj_opt.h:257-261), only the sums enter the gradient
+ * (alm_traj_opt.cpp:341-344) -- out.  store_residuals != 0: hx / gx are written by every call as the reference's function writes them (:835, 846 ...;
+ * read them with uph_batch_download).  `repeat` >= 1 calls inside one launch per trajectory: this is SURVEY.md 8d's "penalty kernel" measured as
+ * north_star defines it (bench.py roofline.penalty_kernel.frac_a5_only).  Any output pointer may be NULL. */
+int uph_penalty_batch(uph_ctx* c, int32_t repeat, int32_t store_residuals, double* cost, double* gdcxy_packed, double* gdcyaw_packed, double* gdT2);
 int uph_init_scaling_batch(uph_ctx* c);
 /* diagnostic: measures the workgroup primitives (barrier, reductions, dependent global load, ...) on the uploaded batch;
  * per-trajectory results via uph_batch_cycles (a -DUPH_CYC=1 build) */

@@ -244,7 +244,10 @@ public:
     // constructMap -- the CSV the reference's own constructMapInput reads (six significant digits) -- plus the side-car.
     bool loadMap(const std::string& map_file) {
         int32_t src = 0;
-        return uph_map_load_cache(m_, map_file.c_str(), (map_file + ".bin").c_str(), &src) == UPH_OK;
+        const int rc = uph_map_load_cache(m_, map_file.c_str(), (map_file + ".bin").c_str(), &src);
+        if (rc == UPH_ERR_NO_CACHE) return false;      // build the map; every other failure surfaces instead of triggering a rebuild that overwrites the cache
+        if (rc != UPH_OK) throw std::runtime_error(std::string("uph_map_load_cache: ") + uph_last_error());
+        return true;
     }
     void saveMap(const std::string& map_file, bool with_sidecar = true) {
         const std::string bin = map_file + ".bin";

@@ -162,6 +162,70 @@ def test_init_with_map_file_cache(tmp_path):
     assert np.abs(c.map_buffer - built).max() < 1e-5 * max(1.0, np.abs(built).max()) and not np.array_equal(c.map_buffer, built)
     pos = np.array([[0.3, -0.2, 0.5]])
     assert np.abs(c.getAllWithGrad(pos)[0] - a.getAllWithGrad(pos)[0]).max() < 1e-4
+    # the side-car WITHOUT its CSV is no cache -- the reference rebuilds whenever map_file is absent (uneven_map.cpp:166-167,
+    # 270-277), so deleting hill.map to force a rebuild must not resurrect hill.map.bin.  A doctored side-car proves which source was used.
+    U.UnevenMap(prm).init(xyz=xyz, map_file=path)                  # (the CSV exists: nothing is rebuilt or rewritten)
+    a.save_cache(path)                                             # both files again
+    doctored = built.copy()
+    doctored[:, 1] = 0.123
+    from uneven_planner_amd.host_map import HostGridView
+    HostGridView(doctored, 4.0, 4.0).write_map_binary(path + ".bin")
+    os.remove(path)
+    import ctypes as C
+    src = C.c_int32(0)
+    e = U.UnevenMap(prm)
+    assert e.L.uph_map_load_cache(e.h, path.encode(), (path + ".bin").encode(), C.byref(src)) == U._lib.UPH_ERR_NO_CACHE
+    assert e.L.uph_map_load_cache(e.h, None, (path + ".bin").encode(), C.byref(src)) == 0 and src.value == 2      # the side-car alone only when no CSV is named
+    d = U.UnevenMap(prm).init(xyz=xyz, map_file=path)              # rebuilt from the cloud; both files rewritten
+    assert np.array_equal(d.map_buffer, built) and os.path.exists(path)
+    assert np.array_equal(U.UnevenMap(prm).init(map_file=path).map_buffer, built)
+    # ... and a failure that is not "no cache" surfaces instead of triggering a rebuild that overwrites the user's files
+    tile = U.UnevenMap(prm, tile=(10, 30))
+    with pytest.raises(U._lib.UnevenHipError):
+        tile.load_cache(path)
+
+
+def test_map_cache_of_a_device_built_slab_against_the_oracles_writer_and_reader(tmp_path, oracle):
+    """VERDICT r05 item 9 (row N3 on the GPU tier against the oracle, not a round trip): the bytes uph_map_save_cache writes for a DEVICE-BUILT map
+    equal the oracle's writer (the reference's `to txt` block, uneven_map.cpp:400-412) on the same cells, and the cells uph_map_load_cache puts on
+    the device from a shuffled, partial file with out-of-range and short lines equal the oracle's reader (constructMapInput, :270-315) -- cells,
+    c_buffer and occupancy as the device commits them"""
+    import ctypes as C
+    import uneven_planner_amd as U
+    from uneven_planner_amd import scenes
+    xyz = scenes.make_hill_cloud(n_side=120, half=2.0)
+    prm = dict(map_size_x=4.0, map_size_y=4.0)
+    m = U.UnevenMap(prm)
+    m.build(xyz)                                                    # plane fits on the device
+    p_dev, p_or = str(tmp_path / "dev.map"), str(tmp_path / "oracle.map")
+    m.save_cache(p_dev)
+    OL = oracle.lib()
+    g = oracle.OracleGrid(size_x=4.0, size_y=4.0)
+    g.set_cells(m.map_buffer)
+    assert OL.orc_map_write_csv(g.h, p_or.encode()) == 0
+    assert open(p_dev, "rb").read() == open(p_or, "rb").read()      # byte for byte: 80 x 80 x 64 lines of the reference's ostream form
+    # the reader: a third of the lines, shuffled, plus lines the reference drops or half-reads
+    rng = np.random.default_rng(4)
+    lines = open(p_dev).read().splitlines()
+    keep = [lines[i] for i in rng.permutation(len(lines))[: len(lines) // 3]]
+    nx, ny, nw = (int(v) for v in g.dims)
+    keep += ["%d,0,0,1,2,0.1,0.2" % nx, "-1,0,0,1,2,0.1,0.2", "0,0,%d,1,2,0.1,0.2" % nw, "3,4", "", keep[0].rsplit(",", 4)[0] + ",9.5,0.125,0.25,-0.5"]
+    p_part = str(tmp_path / "partial.map")
+    open(p_part, "w").write("\n".join(keep) + "\n")
+    src = C.c_int32(0)
+    m2 = U.UnevenMap(prm)
+    U._lib.check(m2.L.uph_map_load_cache(m2.h, p_part.encode(), None, C.byref(src)), "uph_map_load_cache")
+    assert src.value == 1
+    m2.download()
+    g3 = oracle.OracleGrid(size_x=4.0, size_y=4.0)
+    assert OL.orc_map_read_csv(g3.h, p_part.encode()) == 0
+    want, want_c = g3.get_cells()
+    assert np.array_equal(m2.map_buffer.reshape(-1, 4), want)
+    assert np.array_equal(m2.c_buffer.reshape(-1), want_c)
+    g3.compute_occ(min_cnormal=m2.params["min_cnormal"], max_rho=m2.params["max_rho"])
+    occ, occ2 = g3.get_occ()
+    assert np.array_equal(m2.occ_buffer.reshape(-1).astype(np.int8), np.asarray(occ).reshape(-1).astype(np.int8))
+    assert np.array_equal(m2.occ_r2_buffer.reshape(-1).astype(np.int8), np.asarray(occ2).reshape(-1).astype(np.int8))
 
 
 def test_terrain_pose_query_matches_the_oracle_terrain(oracle, analytic_cells):

@@ -86,6 +86,46 @@ def test_single_evaluation_matches_oracle(dev, oracle, oracle_grid, hill_problem
         assert abs(out[i]["T_xy"] - txy) < 1e-13 and abs(out[i]["jerk_cost"] - jc) / jc < 1e-9
 
 
+def test_penalty_kernel_alone_matches_the_oracles_calConstrainCostGrad(dev, oracle, oracle_grid, hill_problem, small_problems):
+    """row A5 by itself (uph_penalty_batch, MODE 8): calConstrainCostGrad (alm_traj_opt.cpp:663-991) on resident coefficients -> cost, gdCxy, gdCyaw,
+    sum gdTxy, sum gdTyaw and -- as the reference's function does on every call -- hx / gx, against the oracle's restatement of that function alone
+    (no jerk terms, no MINCO adjoint).  Random duals (both PHR branches), scales, scale_fx; `repeat` calls in a launch give the same result as one."""
+    _, opt = dev
+    probs = [hill_problem] + small_problems
+    rng = np.random.default_rng(17)
+    K1 = 17
+    lam, mu, sc = [], [], []
+    for p in probs:
+        S = (p["inner_xy"].shape[1] + 1) * K1
+        lam.append(rng.normal(size=S) * 0.1)
+        mu.append(np.abs(rng.normal(size=6 * S)) * 0.1 * (rng.uniform(size=6 * S) < 0.7))      # zeros too: the -mu^2 / (2 rho) branch
+        sc.append(rng.uniform(0.2, 1.0, size=7 * S))
+    sfx = rng.uniform(0.1, 1.0, size=len(probs))
+    opt.upload(probs)
+    opt.set_state(lam=lam, mu=mu, scale_cx=sc, scale_fx=sfx, rho=np.full(len(probs), 3.0))
+    opt.eval_batch(opt.x0_packed(probs))                      # leaves the coefficients and durations of x0 resident
+    sc2 = [rng.uniform(0.2, 1.0, size=v.size) for v in sc]    # other scales than the evaluation's: the residuals A5 stores below are its own,
+    opt.set_state(scale_cx=sc2)                               # not the ones uph_eval_batch left on the device
+    one = opt.penalty_batch(repeat=1, store_residuals=True)
+    out = opt.download()
+    many = opt.penalty_batch(repeat=3, store_residuals=False)
+    for i, p in enumerate(probs):
+        a = oracle.OracleALM(oracle_grid)
+        x0 = a.setup(p)
+        a.set_state(lam=lam[i], mu=mu[i], scale_cx=sc2[i], scale_fx=sfx[i])
+        a.set_rho(3.0)
+        cost, gcx, gtx, gcy, gty = a.constrain(x0)
+        st = a.get_state()
+        d = one[i]
+        assert abs(d["cost"] - cost) / abs(cost) < 1e-9
+        assert rel(gcx, d["gdCxy"]) < 1e-9 and rel(gcy, d["gdCyaw"]) < 1e-9
+        assert abs(d["gdTxy_sum"] - gtx.sum()) / max(1e-300, np.abs(gtx).sum()) < 1e-9
+        assert abs(d["gdTyaw_sum"] - gty.sum()) / max(1e-300, np.abs(gty).sum()) < 1e-9
+        assert rel(st["hx"], out[i]["hx"]) < 1e-9 and rel(st["gx"], out[i]["gx"]) < 1e-9
+        # the repeated, store-free form is the same function: identical bits
+        assert many[i]["cost"] == d["cost"] and np.array_equal(many[i]["gdCxy"], d["gdCxy"]) and np.array_equal(many[i]["gdCyaw"], d["gdCyaw"])
+
+
 def test_init_scaling_matches_oracle(dev, oracle, oracle_grid, hill_problem, small_problems):
     _, opt = dev
     probs = [hill_problem] + small_problems

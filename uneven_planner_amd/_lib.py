@@ -130,6 +130,7 @@ SYMBOLS = {
     "uph_batch_prepare_ms": (C.c_int, [_VP, DP]),
     "uph_batch_cycles": (C.c_int, [_VP, C.POINTER(C.c_longlong)]),
     "uph_eval_batch": (C.c_int, [_VP, DP, DP, DP, _I32]),
+    "uph_penalty_batch": (C.c_int, [_VP, _I32, _I32, DP, DP, DP, DP]),
     "uph_init_scaling_batch": (C.c_int, [_VP]),
     "uph_microbench_batch": (C.c_int, [_VP, _I32]),
     "uph_batch_set_state": (C.c_int, [_VP, DP, DP, DP, DP, DP]),
@@ -150,6 +151,9 @@ SYMBOLS = {
 }
 
 _LIB = None
+
+
+UPH_ERR_NO_CACHE = -5      # include/uneven_hip.h: uph_map_load_cache found no readable cache (build the map)
 
 
 class UnevenHipError(RuntimeError):

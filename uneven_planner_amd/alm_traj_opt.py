@@ -334,6 +334,18 @@ class ALMTrajOpt:
             o += s["n"]
         return f, gs
 
+    def penalty_batch(self, repeat=1, store_residuals=True):
+        """calConstrainCostGrad alone (alm_traj_opt.cpp:663-991) on the resident coefficients / durations / duals / scales: per trajectory
+        (cost, gdCxy (6 Nxy, 2), gdCyaw (6 Nyaw,), sum gdTxy, sum gdTyaw)"""
+        ncx, ncy = sum(12 * s["Nxy"] for s in self._sizes), sum(6 * s["Nyaw"] for s in self._sizes)
+        cost, gx, gy, gt = np.zeros(self._B), np.zeros(ncx), np.zeros(ncy), np.zeros((self._B, 2))
+        _lib.check(self.L.uph_penalty_batch(self.h, int(repeat), int(bool(store_residuals)), _dp(cost), _dp(gx), _dp(gy), _dp(gt)), "uph_penalty_batch")
+        out, ox, oy = [], 0, 0
+        for b, s in enumerate(self._sizes):
+            out.append(dict(cost=cost[b], gdCxy=gx[ox:ox + 12 * s["Nxy"]].reshape(-1, 2).copy(), gdCyaw=gy[oy:oy + 6 * s["Nyaw"]].copy(), gdTxy_sum=gt[b, 0], gdTyaw_sum=gt[b, 1]))
+            ox += 12 * s["Nxy"]; oy += 6 * s["Nyaw"]
+        return out
+
     def init_scaling_batch(self):
         _lib.check(self.L.uph_init_scaling_batch(self.h), "uph_init_scaling_batch")
 

@@ -771,7 +771,7 @@ int uph_map_save_cache(uph_map* m, const char* csv_path, const char* bin_path) {
 }
 // load = constructMapInput: the side-car when bin_path names a readable one for this grid (bit-exact), else the CSV (six digits); the cells
 // go to the device and the map commits (c, occupancy).  source (may be NULL): 2 = side-car, 1 = CSV.  UPH_ERR_INVALID when neither file can
-// be opened -- the caller then builds the map, as `if (!constructMapInput()) constructMap()` does.
+// be opened (UPH_ERR_NO_CACHE) -- the caller then builds the map, as `if (!constructMapInput()) constructMap()` does.
 int uph_map_load_cache(uph_map* m, const char* csv_path, const char* bin_path, int32_t* source) {
     if (!m || (!csv_path && !bin_path)) { setError("uph_map_load_cache: bad arguments"); return UPH_ERR_INVALID; }
     if (m->g.nx_hold != m->g.nx) { setError("uph_map_load_cache: a tile holds only part of the grid"); return UPH_ERR_INVALID; }
@@ -781,15 +781,19 @@ int uph_map_load_cache(uph_map* m, const char* csv_path, const char* bin_path, i
     int src = 0;
     // the CSV is the source of truth (the reference's own cache): the side-car stands in for it only while it is at least as new -- a `.map`
     // regenerated later (by the reference, from another cloud or other ellipsoid parameters) wins over a stale side-car
+    // A named CSV that does not exist means NO cache, whatever side-car lies next to it: the reference rebuilds whenever map_file is absent
+    // (uneven_map.cpp:166-167, 270-277), so deleting `hill.map` to force a rebuild -- or pointing map_file at another cloud's name -- must not
+    // resurrect a stale `hill.map.bin`.  The side-car alone is loaded only when the caller names no CSV at all.
     bool bin_fresh = bin_path != nullptr;
     if (bin_path && csv_path) {
         struct stat sb, sc;
-        if (stat(bin_path, &sb) == 0 && stat(csv_path, &sc) == 0 &&
-            (sb.st_mtim.tv_sec < sc.st_mtim.tv_sec || (sb.st_mtim.tv_sec == sc.st_mtim.tv_sec && sb.st_mtim.tv_nsec < sc.st_mtim.tv_nsec))) bin_fresh = false;
+        if (stat(csv_path, &sc) != 0) bin_fresh = false;
+        else if (stat(bin_path, &sb) == 0 &&
+                 (sb.st_mtim.tv_sec < sc.st_mtim.tv_sec || (sb.st_mtim.tv_sec == sc.st_mtim.tv_sec && sb.st_mtim.tv_nsec < sc.st_mtim.tv_nsec))) bin_fresh = false;
     }
     if (bin_fresh && uph_map_load_bin(bin_path, d, cells.data()) == UPH_OK) src = 2;
     if (!src && csv_path && uph_map_load_csv(csv_path, d, cells.data(), nullptr, nullptr) == UPH_OK) src = 1;
-    if (!src) { setError(std::string("uph_map_load_cache: no readable cache (") + uph_last_error() + ")"); return UPH_ERR_INVALID; }
+    if (!src) { setError(std::string("uph_map_load_cache: no readable cache (") + uph_last_error() + ")"); return UPH_ERR_NO_CACHE; }
     if (source) *source = src;
     return uph_map_set_cells(m, cells.data());
 }

@@ -428,10 +428,13 @@ struct Solver {
 
     // one constraint sample of calConstrainCostGrad (alm_traj_opt.cpp:716-988).  acc[0] += cost, acc[1] += gdTxy part, acc[2] += gdTyaw part.
     // The residuals hx / gx (alm_traj_opt.cpp:835, 846 ...) are consumed only by the dual update after an L-BFGS pass, so the
-    // evaluations of the pass do not store them (7 stores per sample and their drain at the chunk barrier): RES_ONLY = true is the
+    // evaluations of the pass do not store them (7 stores per sample and their drain at the chunk barrier): RES = 1 is the
     // same code up to the residuals, run once over the last evaluated trajectory when the pass ends (refreshResiduals).
-    template <bool RES_ONLY, class R = double>
+    // RES: 0 = cost and gradient, no residual stores (the solve's evaluations); 1 = residuals only; 2 = both -- calConstrainCostGrad as the
+    // reference runs it, hx / gx written by every call (penaltyOnly, the A5-alone measurement entry).
+    template <int RES, class R = double>
     UPH_HD void sampleEval(int s, int slot, double* acc) {
+        constexpr bool RES_ONLY = RES == 1;
         const int i = divSmall(s, K + 1, inv_k1), j = s - i * (K + 1);
         // all 14 dual / scale operands are fetched up front: they are independent of the kinematics, their HBM/L2 latency overlaps
         // the polynomial evaluation and the terrain gather instead of serialising round trips
@@ -467,10 +470,10 @@ struct Solver {
         const R g5 = (Pm.min_cxi - cos_xi) * sc7[5];
         const R sc6 = Pm.use_scaling ? sc7[6] : R(sig_scale);
         const R g6 = (sigma - Pm.max_sig) * sc6;
-        if (RES_ONLY) {
+        if (RES != 0) {
             res[0 * S + s] = h; res[1 * S + s] = g1; res[2 * S + s] = g2; res[3 * S + s] = g3;
             res[4 * S + s] = g4; res[5 * S + s] = g5; res[6 * S + s] = g6;
-            return;
+            if (RES_ONLY) return;
         }
         const R alpha = ec_invK * j;                               // :718  (1.0 / K * j)
         const R gravity = grid.gravity;
@@ -1450,6 +1453,40 @@ struct Solver {
         wg.pfor(n, [&](int t) { bd.gout[td.off_x + t] = g[t]; });
         storeTrajectory(st);
         wg.pfor(1, [&](int) { st.f = f; });
+    }
+    // A5 ALONE -- calConstrainCostGrad (alm_traj_opt.cpp:663-991) and nothing else of innerCallback: the resident coefficients and piece durations of
+    // the last evaluation (bd.cxy / bd.cyaw, TrajState::T_xy / T_yaw; duals, scales, rho, scale_fx resident as well) in -> cost, gdCxy, gdCyaw,
+    // sum_i gdTxy(i), sum_i gdTyaw(i) out (uniform durations: only the sums enter the gradient, :341-344), and -- STORE_RES -- hx / gx written by
+    // every call as the reference writes them (:835, 846 ...).  No MINCO generate / expand, no adjoint, no jerk terms: G starts from zero.
+    // `repeat` calls per launch (SURVEY.md 8d's "penalty kernel" measured as north_star defines it: uph_penalty_batch).
+    template <bool STORE_RES>
+    UPH_HD void penaltyOnly(TrajState& st, int repeat) {
+        rho = wg.bcast(st.rho); scale_fx = wg.bcast(st.scale_fx);
+        Txy = wg.bcast(st.T_xy); Tyaw = wg.bcast(st.T_yaw);
+        ec_iTyaw = wg.bcast(1.0 / Tyaw);
+        const double* oc = bd.cxy + td.off_cxy;
+        const double* oy = bd.cyaw + td.off_cyaw;
+        const int nc = 12 * Nxy + 6 * Nyaw;
+        wg.pfor(nc, [&](int t) { if (t < 12 * Nxy) cxy[t] = oc[t]; else cyaw[t - 12 * Nxy] = oy[t - 12 * Nxy]; });
+        double sm[3] = {0.0, 0.0, 0.0};
+        for (int r = 0; r < repeat; r++) {
+            wg.pfor(nc + 2, [&](int t) { if (t < 12 * Nxy) Gxy[t] = 0.0; else if (t < nc) Gyaw[t - 12 * Nxy] = 0.0; else fillTimes(t - nc); });
+            evalConsts();
+            wg.template accBegin<3>();
+            for (int s0 = 0; s0 < S; s0 += CHS) {
+                const int cnt = S - s0 < CHS ? S - s0 : CHS;
+                wg.template accChunk<3>(cnt, [&](int t, double* acc) { sampleEval<STORE_RES ? 2 : 0, SR>(s0 + t, t, acc); });
+                scatterChunk(s0, cnt);
+            }
+            wg.template accEnd<3>(sm);
+        }
+        double* ogx = bd.pen_gxy + td.off_cxy;
+        double* ogy = bd.pen_gyaw + td.off_cyaw;
+        wg.pfor(nc + 1, [&](int t) {
+            if (t < 12 * Nxy) ogx[t] = Gxy[t];
+            else if (t < nc) ogy[t - 12 * Nxy] = Gyaw[t - 12 * Nxy];
+            else { double* o = bd.pen_out + (size_t)bidx * 3; o[0] = sm[0]; o[1] = sm[1]; o[2] = sm[2]; }
+        });
     }
     UPH_HD void scalingOnly(TrajState& st) {
         const double* gx0 = bd.x + td.off_x;

@@ -620,7 +620,8 @@ struct DevWG {
 
 // MODE 0: one (or `repeat`) objective evaluation(s)   1: reset + initScaling   2: ALM / L-BFGS solve (repeat > 0: at most that many ALM passes)
 // 3: post-solve report   4: initScaling only (test hook, keeps the resident duals)   5: phase microbenchmark
-// 7: continue the L-BFGS loop from a host-given state (test hook; repeat = 2 * budget + finish_pass).  A compile-time MODE gives each phase its own register budget.
+// 7: continue the L-BFGS loop from a host-given state (test hook; repeat = 2 * budget + finish_pass).  8: calConstrainCostGrad alone (uph_penalty_batch; repeat = 2 * calls + store_residuals).
+// A compile-time MODE gives each phase its own register budget.
 // F32S: the sample phase of every objective evaluation computes in fp32 (Solver<WG, f32r>; BASELINE.json configs[4] "fp32"), everything else
 // -- MINCO, L-BFGS, ALM, the scatter and the accumulations -- stays fp64.  Own instantiations: the fp64 kernels are untouched by it.
 template <int NT, int WPS, int MODE, bool F32S = false>
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(NT, WPS) void uph_solver_kernel(GridDev grid, OptPa
     else if (MODE == 1) sol.prepare(st);
     else if (MODE == 2) sol.optimize(st, repeat);
     else if (MODE == 7) sol.resumeHook(st, repeat >> 1, repeat & 1);
+    else if (MODE == 8) { if (repeat & 1) sol.template penaltyOnly<true>(st, repeat >> 1); else sol.template penaltyOnly<false>(st, repeat >> 1); }
     else if (MODE == 3) sol.report(st);
     else if (MODE == 5) sol.microbench(st, repeat);
     else sol.scalingOnly(st);
@@ -659,6 +661,10 @@ __global__ void uph_terrain_kernel(GridDev grid, const double* __restrict__ pos,
     }
 }
 
+#ifdef UPH_ONE_KERNEL
+// device-only build of ONE instantiation (tools/one_kernel.sh: registers, spills and ISA of a kernel in seconds instead of the whole library's minutes)
+template __global__ void uph_solver_kernel<UPH_OK_NT, UPH_OK_WPS, UPH_OK_MODE, false>(GridDev, OptParams, BatchDev, int);
+#else
 // ------------------------------------------------------------------------------------------------ host side
 namespace uph {
 thread_local std::string g_last_error;
@@ -739,6 +745,7 @@ struct uph_ctx {
     DevBuf d_thomas, d_rsd, d_rs, d_gridmem, d_parammem;
     GridDev grid_host;                      // source of the descriptor copy (outlives the asynchronous copy)
     DevBuf d_desc, d_state, d_x, d_x0, d_gout, d_dual, d_res, d_scl, d_cxy, d_cyaw, d_hist, d_report, d_order, d_trace;
+    DevBuf d_pen_gxy, d_pen_gyaw, d_pen_out;      // uph_penalty_batch outputs (allocated at its first call)
     int trace_cap = 0;                      // requested for the next upload
     int trace_cap_up = 0;                   // what the uploaded batch's trace buffer was sized for
     std::vector<TrajState> state_host;
@@ -769,6 +776,7 @@ static BatchDev makeBatchDev(uph_ctx* c) {
     bd.cxy = c->d_cxy.as<double>(); bd.cyaw = c->d_cyaw.as<double>();
     bd.hist = c->d_hist.as<double>();
     bd.report = c->d_report.as<double>();
+    bd.pen_gxy = c->d_pen_gxy.as<double>(); bd.pen_gyaw = c->d_pen_gyaw.as<double>(); bd.pen_out = c->d_pen_out.as<double>();
     bd.trace = c->trace_cap_up > 0 ? c->d_trace.as<double>() : nullptr;
     bd.trace_cap = c->trace_cap_up;
     bd.order = c->d_order.as<int>();
@@ -882,6 +890,12 @@ static int launchSolver(uph_ctx* c, int mode, int repeat, bool async = false, hi
         else if (c->lanes == 256) UPH_LAUNCH(256, 1, 7);
         else { setError("the L-BFGS resume hook is built for 128 and 256 lanes"); return UPH_ERR_INVALID; }
     }
+    else if (mode == 8) {
+        if (c->lanes == 128) UPH_LAUNCH(128, 2, 8);
+        else if (c->lanes == 256) UPH_LAUNCH(256, 1, 8);
+        else if (c->lanes == 512) UPH_LAUNCH(512, 1, 8);
+        else UPH_LAUNCH(64, 1, 8);
+    }
     else if (c->lanes == 64 && c->wps_forced == 2) UPH_LAUNCH_MODE(64, 2);
     else if (c->lanes == 64) UPH_LAUNCH_MODE(64, 1);
     else if (c->lanes == 128 && mode == 1) UPH_LAUNCH(128, 1, 1);      // initScaling without the register cap: 410 VGPRs and no spills instead of 162 spilled at 256 (6.05 -> 5.39 ms at B = 8192)
@@ -970,7 +984,8 @@ void uph_ctx_destroy(uph_ctx* c) {
     hipSetDevice(c->device);             // not via c->map: the map may already have been destroyed by the caller
     for (void* p : c->op_allocs) hipFree(p);
     DevBuf* bufs[] = {&c->d_ops, &c->d_desc, &c->d_state, &c->d_x, &c->d_gout, &c->d_dual, &c->d_res, &c->d_scl, &c->d_cxy, &c->d_cyaw,
-                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas, &c->d_rsd, &c->d_rs, &c->d_gridmem, &c->d_parammem};
+                      &c->d_hist, &c->d_report, &c->d_order, &c->d_trace, &c->d_x0, &c->d_thomas, &c->d_rsd, &c->d_rs, &c->d_gridmem, &c->d_parammem,
+                      &c->d_pen_gxy, &c->d_pen_gyaw, &c->d_pen_out};
     for (DevBuf* b : bufs) b->release();
     HostBuf* hbufs[] = {&c->h_x, &c->h_cxy, &c->h_cyaw, &c->h_dual, &c->h_res, &c->h_scl};
     for (HostBuf* b : hbufs) b->release();
@@ -1506,6 +1521,33 @@ int uph_eval_batch(uph_ctx* c, const double* x_packed, double* f, double* grad_p
     return UPH_OK;
 }
 
+// A5 alone -- calConstrainCostGrad (alm_traj_opt.cpp:663-991): the coefficients, piece durations, duals, scales, rho and scale_fx RESIDENT on the device
+// (i.e. those of the last uph_eval_batch / solve of this batch) in -> cost [B], gdCxy [sum 12 Nxy] (row 6 i + k, column dim: the reference's 6N x 2
+// block row-major), gdCyaw [sum 6 Nyaw], gdT [B][2] = (sum_i gdTxy(i), sum_i gdTyaw(i)) out; store_residuals != 0: hx / gx are written by every call,
+// as the reference's function writes them (read them with uph_batch_download).  `repeat` calls inside one launch (measurement); any output may be NULL.
+int uph_penalty_batch(uph_ctx* c, int32_t repeat, int32_t store_residuals, double* cost, double* gdcxy_packed, double* gdcyaw_packed, double* gdT2) {
+    if (c && c->n_rejected) { setError("packed-array hooks need a batch without unsupported problems (uph_result.ret_code == UPH_RET_UNSUPPORTED)"); return UPH_ERR_INVALID; }
+    if (!c || c->B <= 0 || repeat < 1 || repeat > (1 << 20)) { setError("uph_penalty_batch: bad arguments"); return UPH_ERR_INVALID; }
+    HIPCHK(hipSetDevice(uphMapDevice(c->map)));
+    if (c->d_pen_gxy.ensure(8 * c->sum_cxy) || c->d_pen_gyaw.ensure(8 * c->sum_cyaw) || c->d_pen_out.ensure(8 * 3 * (size_t)c->B)) return UPH_ERR_HIP;
+    int r = launchSolver(c, 8, 2 * repeat + (store_residuals ? 1 : 0));
+    if (r != UPH_OK) return r;
+    if (cost || gdT2) {
+        std::vector<double> o3((size_t)3 * c->B);
+        HIPCHK(hipMemcpy(o3.data(), c->d_pen_out.p, 8 * o3.size(), hipMemcpyDeviceToHost));
+        for (int b = 0; b < c->B; b++) {
+            if (cost) cost[b] = o3[3 * (size_t)b];
+            if (gdT2) { gdT2[2 * (size_t)b] = o3[3 * (size_t)b + 1]; gdT2[2 * (size_t)b + 1] = o3[3 * (size_t)b + 2]; }
+        }
+    }
+    if (gdcxy_packed) HIPCHK(hipMemcpy(gdcxy_packed, c->d_pen_gxy.p, 8 * c->sum_cxy, hipMemcpyDeviceToHost));
+    if (gdcyaw_packed) HIPCHK(hipMemcpy(gdcyaw_packed, c->d_pen_gyaw.p, 8 * c->sum_cyaw, hipMemcpyDeviceToHost));
+    c->last_evals = (int64_t)c->B * repeat;
+    c->last_sample_evals = c->sum_S * repeat;
+    c->last_iters = 0; c->last_hist_bytes = 0;
+    return UPH_OK;
+}
+
 // diagnostic: cost of the workgroup primitives (see Solver::microbench); read the result with uph_batch_cycles
 int uph_microbench_batch(uph_ctx* c, int32_t reps) {
     if (!c || c->B <= 0 || reps < 1) return UPH_ERR_INVALID;
@@ -1648,3 +1690,4 @@ int uph_terrain_query(uph_map* m, const double* pos, int32_t n, double* values7,
 }
 
 }  // extern "C"
+#endif      // UPH_ONE_KERNEL

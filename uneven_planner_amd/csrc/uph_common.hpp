@@ -167,6 +167,9 @@ struct BatchDev {
     double* rs_d;       // test hook (teacher-forced L-BFGS state): direction vectors [sum n]
     double* rs;         // ... and 24 scalars per trajectory (Solver::resumeHook)
     double* report;     // [B*7]
+    double* pen_gxy;    // uph_penalty_batch (Solver::penaltyOnly): gdCxy [sum 12 Nxy], gdCyaw [sum 6 Nyaw], (cost, sum gdTxy, sum gdTyaw) [B*3]
+    double* pen_gyaw;
+    double* pen_out;
     double* trace;      // optional [B*trace_cap] diagnostic cost trace (nullptr = off)
     int trace_cap;
     const int* order;   // optional launch order: workgroup w solves trajectory order[w] (longest first)

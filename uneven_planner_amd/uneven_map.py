@@ -347,8 +347,9 @@ class UnevenMap:
         """constructMapInput: False when neither `map_file` nor `map_file.bin` can be read; self.cache_source = "bin" / "csv" otherwise"""
         src = C.c_int32(0)
         rc = self.L.uph_map_load_cache(self.h, map_file.encode(), (map_file + ".bin").encode(), C.byref(src))
-        if rc != 0:
-            return False
+        if rc == _lib.UPH_ERR_NO_CACHE:      # no readable cache: the caller builds the map.  Anything else (tile map, host memory, HIP) is a failure,
+            return False                     # not a reason to rebuild and overwrite the user's cache files
+        _lib.check(rc, "uph_map_load_cache")
         self.cache_source = {1: "csv", 2: "bin"}[src.value]
         self.download()
         self.map_ready = True
