@@ -221,7 +221,7 @@ def test_map_cache_of_a_device_built_slab_against_the_oracles_writer_and_reader(
     assert OL.orc_map_read_csv(g3.h, p_part.encode()) == 0
     want, want_c = g3.get_cells()
     assert np.array_equal(m2.map_buffer.reshape(-1, 4), want)
-    assert np.array_equal(m2.c_buffer.reshape(-1), want_c)
+    assert np.abs(m2.c_buffer.reshape(-1) - want_c).max() < 4e-16      # c = sqrt(1 - |zb|^2) is formed on the device at commit (an fma in the radicand): last-bit differences
     g3.compute_occ(min_cnormal=m2.params["min_cnormal"], max_rho=m2.params["max_rho"])
     occ, occ2 = g3.get_occ()
     assert np.array_equal(m2.occ_buffer.reshape(-1).astype(np.int8), np.asarray(occ).reshape(-1).astype(np.int8))

@@ -14,10 +14,13 @@ def main():
     ev = []
     for i in range(start, end):
         l = lines[i].strip()
-        if not l or l.startswith(('.', ';', '//')) or l.split()[0].endswith(':'):
+        if not l or (l.startswith(('.', ';', '//')) and not l.startswith('; UPHMARK')) or l.split()[0].endswith(':'):
             continue
         ninst += 1
         op = l.split()[0]
+        if l.startswith('; UPHMARK'):
+            ev.append((ninst, nval, 'MARK ' + l[10:]))
+            continue
         if op.startswith('v_'):
             nval += 1
         if op == 's_barrier':
@@ -36,7 +39,7 @@ def main():
     # compress runs of scratch ops
     out = []
     for e in ev:
-        kind = e[2].split()[0]
+        kind = e[2].split()[0] if not e[2].startswith('MARK') else e[2]
         if out and kind.startswith('scratch_') and out[-1][2] == kind and e[0] - out[-1][4] < 40:
             out[-1][3] += 1
             out[-1][4] = e[0]

@@ -197,6 +197,7 @@ struct Solver {
     // d and stores its own knot), which spares the search a pass and a barrier per trial.
     template <bool STEP>
     UPH_HD void generate(double* xin, double st) {
+        UPH_MARK("generate");
         const long long tsub_start = wg.clock();
         const double tau_ = STEP ? fma(st, d[0], xp[0]) : xin[0];
         const double Ttot = expC2(tau_);
@@ -243,6 +244,7 @@ struct Solver {
     // (:722-734) -- the coefficients are still in registers.  Two more lanes fill the sample-time tables.
     // out[0] = energy_xy + energy_yaw, out[1] = sum_i gdT_xy(i), out[2] = sum_i gdT_yaw(i)   (unscaled)
     UPH_HD void expand(const double* xin, double jerk_w, double out[3]) {
+        UPH_MARK("expand");
         const long long t0 = wg.clock();
         const double Tx = Txy, Ty = Tyaw, itx = wg.bcast(1.0 / Tx), ity = wg.bcast(1.0 / Ty);
         const double* zxy = rec;
@@ -387,8 +389,10 @@ struct Solver {
         S_.lon_acc = S_.acc[0] * S_.cyaw + S_.acc[1] * S_.syaw;
         S_.lat_acc = S_.acc[0] * (-S_.syaw) + S_.acc[1] * S_.cyaw;
         S_.yawn = yawn; S_.cw = cw; S_.sw = sw;
+        UPH_MARK("kin.terrain");
         if constexpr (WITH_GRADS) terrainAllWithGrad(framedGrid(), S_.pos[0], S_.pos[1], yawn, cw, sw, S_.tv, S_.tg);   // :778  (initScaling: R = double)
         else terrainValuesOnly<R>(S_);
+        UPH_MARK("kin.after_terrain");
         S_.vx = S_.v_norm * S_.tv[0];                                   // :813-817
         S_.wz = dyaw * S_.tv[5];
         S_.ax = S_.lon_acc * S_.tv[0] + grid.gravity * S_.tv[1];
@@ -435,14 +439,26 @@ struct Solver {
     template <int RES, class R = double>
     UPH_HD void sampleEval(int s, int slot, double* acc) {
         constexpr bool RES_ONLY = RES == 1;
+        UPH_MARK("sampleEval");
         const int i = divSmall(s, K + 1, inv_k1), j = s - i * (K + 1);
         // all 14 dual / scale operands are fetched up front: they are independent of the kinematics, their HBM/L2 latency overlaps
         // the polynomial evaluation and the terrain gather instead of serialising round trips
         R dl[7], sc7[7];
+#if !defined(UPH_LATE_DUALS) || !UPH_LATE_DUALS
 #pragma unroll
         for (int q = 0; q < 7; q++) { dl[q] = R(RES_ONLY ? 0.0 : dual[q * S + s]); sc7[q] = R(scl[q * S + s]); }
+#endif
         KinT<R> k;
         kin<false, R>(i, j, k);
+        UPH_MARK("sampleEval.penalties");
+#if defined(UPH_LATE_DUALS) && UPH_LATE_DUALS
+        {
+            int s_ = s;
+            asm volatile("" : "+v"(s_));           // (opaque: the loads cannot be hoisted above the gather)
+#pragma unroll
+            for (int q = 0; q < 7; q++) { dl[q] = R(RES_ONLY ? 0.0 : dual[q * S + s_]); sc7[q] = R(scl[q * S + s_]); }
+        }
+#endif
         const R icvx = k.tv[0], icvy = k.tv[2], cos_xi = k.tv[4], icxi = k.tv[5], sigma = k.tv[6];
         const R vx = k.vx, wz = k.wz, ax = k.ax, ay = k.ay, curv = k.curv_snorm;
         const R nh0 = k.syaw, nh1 = -k.cyaw;
@@ -631,6 +647,7 @@ struct Solver {
     // Every LDS operand is read at base + constant without clamping: reads next to a piece's slots land in neighbouring words of the
     // same allocation (wtab sits right before rec) and are discarded by the selects.
     UPH_HD void scatterChunk(int s0, int cnt) {
+        UPH_MARK("scatterChunk");
         const int K1 = K + 1;
         const double xr = (double)Nxy / (double)Nyaw;       // xy pieces per yaw piece
         const int i0 = s0 / K1, i1 = (s0 + cnt - 1) / K1;
@@ -715,11 +732,14 @@ struct Solver {
             // masked to zero).  The device runs it on the matrix cores (DevWG::scatterXY17, v_mfma_f64_16x16x4_f64) for the reference's
             // int_K = 16 while the other wave(s) sum the yaw blocks; any other K takes the vector path below.
             if (K1 == 17) {
+                UPH_MARK("scatter.mfma");
                 wg.scatterXY17(rec, wtab, Gxy, i0, i1 - i0 + 1, s0, cnt);
+                UPH_MARK("scatter.yaw");
                 wg.pforRev(3 * (m1 - m0 + 1), yawTask);
                 return;
             }
         }
+        UPH_MARK("scatter.vector(cold for K=16)");
         wg.pfor(XYL + 3 * (m1 - m0 + 1), [&](int t) {
             if (t < XYL) { if (t < nxyt) xyTask(t); }
             else yawTask(t - XYL);
@@ -732,6 +752,7 @@ struct Solver {
     // gout != nullptr: the way-point entries of the gradient are written straight from gamma (alm_traj_opt.cpp:336-337) and gd_out
     // receives sum_{t >= 1} gout[t] d[t] (the caller adds the tau entry): g . d for the line search without a pass of its own.
     UPH_HD void adjoint(double& chain_xy, double& chain_yaw, double* gout = nullptr, double* gd_out = nullptr) {
+        UPH_MARK("adjoint");
         const double Tx = Txy, Ty = Tyaw, itx = wg.bcast(1.0 / Txy), ity = wg.bcast(1.0 / Tyaw);
         const long long ta0 = wg.clock();
         const int nbx = Nxy + 5, nby = Nyaw + 5;
@@ -829,6 +850,7 @@ struct Solver {
     // hx / gx of the LAST evaluated trajectory (Q1: the coefficients in LDS are those of the last evaluation, also after a failed
     // line search restored x), for updateDualVars / judgeConvergence / the caller
     UPH_HD void refreshResiduals() {
+        UPH_MARK("refreshResiduals");
         wg.pfor(2, [&](int u) { fillTimes(u); });          // adjoint() has overwritten the tables with gamma
         wg.pfor(S, [&](int s) { double dummy[3]; sampleEval<true>(s, 0, dummy); });
     }
@@ -1214,6 +1236,7 @@ struct Solver {
                 double* sc = hr + 2;
                 double* yc = hr + 2 + hnp;
                 const double pf_old = (0 < P.past && P.past <= k) ? wg.bcast(pf[k % P.past]) : 0.0;      // read before the pass' barrier: lane 0 may overwrite it afterwards
+                UPH_MARK("lbfgs.bookkeeping");
                 double r5[5], mx2[2];
                 wg.template sumMax<5, 2>(n, r5, mx2, [&](int i, double* acc, double* mx) {
                     const double xv = x[i], gv = g[i], xo = xp[i], go = gp[i];
@@ -1254,6 +1277,7 @@ struct Solver {
                     // two-loop recursion (lbfgs.hpp:687-710): a serial chain of 2*bound dot/axpy steps over the history in HBM
                     const long long tq = wg.clock();
                     cyc[7] += tq - t_last_eval_end;                 // end of evaluation -> start of the two-loop
+                    UPH_MARK("twoLoop");
                     wg.twoLoop(d, g, n, hist, pf + MAX_PAST, rec, m, end, bound, ys / yy);   // (the record buffer is idle here: it parks the alphas)
                     dginit = wg.bcast(pf[MAX_PAST]);                // g . d, left by the two-loop
                     t_last_eval_end = wg.clock();
@@ -1271,6 +1295,7 @@ struct Solver {
 
     // ------------------------------------------------------------------ ALM helpers (alm_traj_opt.h:132-151)
     UPH_HD void updateDualVars() {
+        UPH_MARK("updateDualVars");
         const double r = rho;
         wg.pfor(S, [&](int s) {
             dual[s] += r * res[s];

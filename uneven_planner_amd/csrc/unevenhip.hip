@@ -567,6 +567,7 @@ struct DevWG {
     }
     template <bool ADJ>
     __device__ __forceinline__ void thomasT(const double* tab, double* bw, int lenW, double* bx, int lenX) {
+        UPH_MARK("thomas");
         __builtin_amdgcn_s_setprio(3);              // dependency chains: let them win the issue arbitration
         const bool packed = uni(lenW) <= 32 * UPH_THOMAS_KPL - 1 && uni(lenX) <= 16 * UPH_THOMAS_KPL - 1;
         if (packed) {
@@ -663,7 +664,10 @@ __global__ void uph_terrain_kernel(GridDev grid, const double* __restrict__ pos,
 
 #ifdef UPH_ONE_KERNEL
 // device-only build of ONE instantiation (tools/one_kernel.sh: registers, spills and ISA of a kernel in seconds instead of the whole library's minutes)
-template __global__ void uph_solver_kernel<UPH_OK_NT, UPH_OK_WPS, UPH_OK_MODE, false>(GridDev, OptParams, BatchDev, int);
+#ifndef UPH_OK_F32
+#define UPH_OK_F32 false
+#endif
+template __global__ void uph_solver_kernel<UPH_OK_NT, UPH_OK_WPS, UPH_OK_MODE, UPH_OK_F32>(GridDev, OptParams, BatchDev, int);
 #else
 // ------------------------------------------------------------------------------------------------ host side
 namespace uph {

@@ -24,6 +24,14 @@
 #define UPH_AS_GLOBAL(p) (p)
 #endif
 
+// diagnostic builds only (tools/one_kernel.sh ... -DUPH_ISA_MARKS=1): named comments in the compiler's assembly output, so that tools/isa_spills.py can say which
+// phase of the workgroup program a scratch access / a stretch of instructions belongs to.  Empty in every shipped build.
+#if defined(UPH_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define UPH_MARK(name) asm volatile("; UPHMARK " name)
+#else
+#define UPH_MARK(name) do { } while (0)
+#endif
+
 namespace uph {
 
 constexpr int MAX_PIECE_XY = 128;
