@@ -72,25 +72,71 @@ def pmc_traffic(batch, stream_bytes):
     return fetch + min(fetch, 0.5 * stream_bytes) + write, t.get("tag", "profiles/pmc_traffic.json")
 
 
+class Stage:
+    """hard wall-clock limit for one stage of a run (a hung collective or a device that never answers must not park the job until the launcher's own
+    limit): a watchdog thread ends THIS process with exit code 3 and a line on stderr naming the stage.  `with Stage("map build", 300): ...`"""
+    def __init__(self, name, seconds, rank=0):
+        self.name, self.seconds, self.rank = name, float(os.environ.get("UPH_BENCH_STAGE_LIMIT", seconds)), rank
+        self.t0 = 0.0
+
+    def __enter__(self):
+        import threading
+        self.t0 = time.perf_counter()
+        self.done = threading.Event()
+
+        def watch():
+            if not self.done.wait(self.seconds):
+                sys.stderr.write("bench.py: rank %d: stage \"%s\" exceeded its limit of %.0f s -- giving up (exit 3)\n" % (self.rank, self.name, self.seconds))
+                sys.stderr.flush()
+                os._exit(3)
+        threading.Thread(target=watch, daemon=True).start()
+        return self
+
+    def __exit__(self, *exc):
+        self.done.set()
+        self.elapsed = time.perf_counter() - self.t0
+        return False
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` outside a launcher: start N ranks of this script (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_* in their environment, the same contract torch.distributed.run provides), relay rank 0's JSON line, fail if any rank fails."""
+    MASTER_* in their environment, the same contract torch.distributed.run provides), relay rank 0's JSON line, fail if any rank fails.  A rank that
+    dies takes the others with it (they would otherwise wait for it at the next barrier until the collective's own timeout), and the whole job has a
+    wall-clock limit (UPH_BENCH_JOB_LIMIT seconds, default 1500)."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), UPH_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = procs[0].communicate()[0]
-    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
-    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
-    if any(codes) or not line:
-        sys.stderr.write("bench.py: ranks exited with %s\n%s\n" % (codes, out0 or ""))
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    limit = float(os.environ.get("UPH_BENCH_JOB_LIMIT", "1500"))
+    t0 = time.time()
+    why = None
+    while True:
+        codes = [q.poll() for q in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad or time.time() - t0 > limit:
+            why = ("rank(s) %s exited with %s" % (bad, [codes[r] for r in bad])) if bad else ("the job exceeded %.0f s" % limit)
+            for q in procs:              # (exactly the processes started above)
+                if q.poll() is None:
+                    q.kill()
+            codes = [q.wait() for q in procs]
+            break
+        time.sleep(0.2)
+    out0.seek(0)
+    text = out0.read()
+    line = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if why or any(codes) or not line:
+        sys.stderr.write("bench.py: %s; ranks exited with %s\n%s\n" % (why or "a rank failed", codes, text))
         raise SystemExit(1)
     print(line[-1], flush=True)
 
@@ -117,14 +163,31 @@ def single_process(args):
     if torch.cuda.device_count() < N:
         raise SystemExit("bench.py --single-process: --gpus %d but only %d GPU(s) visible" % (N, torch.cuda.device_count()))
     B = args.batch or 16384
+    import ctypes as C
+    import hashlib
+    # the in-library RCCL binding and an all-gather of a known pattern over the clique of the N devices, before anything depends on it
+    selftest = None
+    if N > 1:
+        with Stage("uph_rccl_selftest", 240) as stg:
+            info = C.create_string_buffer(256)
+            rc = U._lib.load().uph_rccl_selftest(N, info, 256)
+        selftest = {"ok": rc == 0, "world": N, "ms": stg.elapsed * 1e3, "info": info.value.decode(errors="replace")}
+        if rc != 0:
+            raise SystemExit("bench.py --single-process: uph_rccl_selftest(%d) failed: %s" % (N, U._lib.load().uph_last_error()))
     xyz = scenes.make_hill_cloud()
     maps = [U.UnevenMap(device=g) for g in range(N)]
-    t0 = time.time()
-    stages = U.UnevenMap.build_multi(maps, xyz)
-    map_build_s = time.time() - t0
-    t0 = time.time()
-    stages2 = U.UnevenMap.build_multi(maps, xyz, download=False)      # second call: the RCCL clique is cached
-    map_build_warm_s = time.time() - t0
+    with Stage("uph_map_build_multi", 300):
+        t0 = time.time()
+        stages = U.UnevenMap.build_multi(maps, xyz)
+        map_build_s = time.time() - t0
+        t0 = time.time()
+        stages2 = U.UnevenMap.build_multi(maps, xyz, download=False)      # second call: the RCCL clique is cached
+        map_build_warm_s = time.time() - t0
+    hashes = [hashlib.sha1(np.ascontiguousarray(mm.map_buffer).tobytes()).hexdigest()[:15] for mm in maps]
+    if len(set(hashes)) != 1:
+        raise SystemExit("bench.py --single-process: the devices hold different grids after uph_map_build_multi: %s" % hashes)
+    if N > 1 and not stages2.get("via_rccl"):
+        sys.stderr.write("bench.py --single-process: the slab exchange did NOT run as an RCCL collective (device-to-device copies instead)\n")
     m0 = maps[0]
     nx, ny = int(m0.voxel_num[0]), int(m0.voxel_num[1])
     gridinfo = (nx, ny, m0.xy_resolution, m0.map_origin[0], m0.map_origin[1])
@@ -146,19 +209,26 @@ def single_process(args):
             o.set_rho(1.0); o.solve_async()
         for o in opts:
             o.wait()
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    kms = []
-    for _ in range(args.steps):
-        step()
-        kms.append([o.stats()["kernel_ms"] for o in opts])
-    sync()
-    dt = time.perf_counter() - t0
+    with Stage("warm-up", 120 + 10 * args.warmup):
+        for _ in range(args.warmup):
+            step()
+        sync()
+    with Stage("timed region", 60 + 10 * args.steps):
+        t0 = time.perf_counter()
+        kms = []
+        for _ in range(args.steps):
+            step()
+            kms.append([o.stats()["kernel_ms"] for o in opts])
+        sync()
+        dt = time.perf_counter() - t0
     rets = np.array([r["ret"] for r in opts[0].download(full=False)])
     res = single_process_line(args, N, B, dt, np.mean(np.array(kms), axis=0), float((rets == 0).mean()), [nx, ny, int(m0.voxel_num[2])], stages, stages2, map_build_s, map_build_warm_s,
                               [mm.build_stats()["stages_ms"] for mm in maps])
+    res["rccl_selftest"] = selftest
+    res["map_hash"] = hashes[0]
+    res["map_hash_identical_on_all_devices"] = True
+    kmean = np.mean(np.array(kms), axis=0)
+    res["per_gpu_kernel_spread"] = float((kmean.max() - kmean.min()) / kmean.max())
     print(json.dumps(res), flush=True)
 
 
@@ -194,6 +264,217 @@ def single_process_dry_run(args):
     print(json.dumps(line), flush=True)
 
 
+def solve_rate(torch, opt, B, K, bytes_per_sample=BYTES_PER_SAMPLE_EVAL):
+    """one warm-up + K timed uph_batch_solve steps of the uploaded batch: throughput, kernel time and the solve kernel's own roofline figure"""
+    opt.set_rho(1.0); opt.solve()
+    torch.cuda.synchronize()
+    ms, prep, se, hb, it, ev = [], [], 0, 0, 0, 0
+    t1 = time.perf_counter()
+    for _ in range(K):
+        opt.set_rho(1.0); opt.solve()
+        st = opt.stats()
+        ms.append(st["kernel_ms"]); prep.append(st["prepare_ms"]); se += st["sample_evals"]; hb += st["hist_bytes"]; it += st["lbfgs_iters"]; ev += st["evals"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    n_mean = sum(s_["n"] for s_ in opt._sizes) / max(1, B)
+    by = (se * bytes_per_sample + hb + it * 2 * 8 * n_mean) / K
+    ach = by / (float(np.mean(ms)) * 1e-3) / 1e9
+    out = opt.download(full=False)
+    return {"value": B * K / dt, "unit": "traj-opts/s", "batch": B, "steps": K, "ms_per_step": dt / K * 1e3, "scaling_kernel_ms": float(np.mean(prep)),
+            "lbfgs_iters_per_traj": it / K / B, "evals_per_traj": ev / K / B, "converged_frac": float(np.mean([o_["ret"] == 0 for o_ in out])),
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": float(np.mean(ms)), "algorithmic_bytes_per_launch": by, "bytes_per_sample_evaluation": bytes_per_sample}}, out
+
+
+def first_eval_parity(U, O, m, og, probs, n=8, window=False):
+    """first objective evaluation after initScaling -- f and the gradient at x0 -- of the first n problems: device (uph_init_scaling_batch + uph_eval_batch)
+    against the CPU oracle (the checker: this leg belongs to cpu_baseline / parity, never to a timed region)"""
+    pp = probs[:n]
+    ev = U.ALMTrajOpt(m)
+    ev.upload(pp)
+    ev.init_scaling_batch()
+    f, g = ev.eval_batch(ev.x0_packed(pp))
+    ef, eg = 0.0, 0.0
+    for i, p in enumerate(pp):
+        g_, q_, _ = O.window_oracle(m, p) if window else (og, p, None)
+        a = O.OracleALM(g_)
+        x0 = a.setup(q_)
+        a.init_scaling(x0)
+        fo, go, _ = a.eval(x0)
+        ef = max(ef, abs(f[i] - fo) / abs(fo))
+        eg = max(eg, float(np.abs(g[i] - go).max() / np.abs(go).max()))
+    return {"problems": len(pp), "f_rel_max": ef, "grad_rel_max": eg, "tolerance": 1e-9, "ok": bool(ef < 1e-9 and eg < 1e-9),
+            "what": "f and grad f of innerCallback at x0 after initScaling, device vs CPU oracle" + (" on the window of cells around each problem" if window else "")}
+
+
+def oracle_baseline(O, make_grid_and_problem, probs, budget_s, what):
+    """the CPU oracle (single thread, kind "port") on the first problems of a batch until ~budget_s seconds are spent"""
+    cdt, n, its, conv = 0.0, 0, 0, 0
+    for p in probs:
+        g_, q_ = make_grid_and_problem(p)
+        t0 = time.perf_counter()
+        r = O.OracleALM(g_).optimize(q_)
+        cdt += time.perf_counter() - t0
+        n += 1; its += r["lbfgs_iters"]; conv += int(r["ret"] == 0)
+        if cdt > budget_s:
+            break
+    return {"value": n / cdt, "unit": "traj-opts/s", "cores": 1, "kind": "port", "sample": "first %d problems of %s, CPU oracle (C++ -O3, single thread), %.1f s" % (n, what, cdt),
+            "ms_per_lbfgs_iter": cdt * 1e3 / max(1, its), "converged_frac": conv / n, "cpu_model": cpu_model()}
+
+
+def measure_configs(args, torch, U, scenes, m_hill, single_line, pk):
+    """Every BASELINE.json config in the driver-run line: one entry per config -- its workload, the measured value, the kernel's
+    roofline figure, a CPU baseline on a bounded sample and a parity statement.  Rank 0, one GPU; none of it is inside the headline's timed region."""
+    from oracle import oracle_py as O
+    try:
+        names = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    except Exception:
+        names = ["configs[%d]" % i for i in range(5)]
+    golden = os.path.join(ROOT, "tests", "golden")
+    cfg = []
+    t_all = time.perf_counter()
+    # ---- [0] hill, single goal, the reference's CPU back-end = the CPU oracle on that goal (the plumbing case)
+    og = O.OracleGrid()
+    og.set_cells(m_hill.map_buffer)
+    hp = scenes.hill_problem()
+    ts, r0 = [], None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r0 = O.OracleALM(og).optimize(hp)
+        ts.append(time.perf_counter() - t0)
+    a = O.OracleALM(og)
+    x0 = a.setup(hp)
+    a.init_scaling(x0)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        a.eval(x0)
+    cpu_eval_us = (time.perf_counter() - t0) / 50 * 1e6
+    cfg.append({"config": names[0], "value": min(ts) * 1e3, "unit": "ms per optimizeSE2Traj call", "higher_is_better": False, "device": "host CPU, one thread (the oracle = kind \"port\"; the reference needs Eigen / ROS and cannot be built here)",
+                "lbfgs_iters": r0["lbfgs_iters"], "ret": r0["ret"], "ms_per_lbfgs_iter": min(ts) * 1e3 / max(1, r0["lbfgs_iters"]), "us_per_objective_evaluation": cpu_eval_us,
+                "cpu_baseline": {"value": 1.0 / min(ts), "unit": "traj-opts/s", "cores": 1, "kind": "port", "sample": "the hill goal, best of 3 solves", "cpu_model": cpu_model()}})
+    # ---- [1] hill, one GPU, single trajectory, batched penalty kernel
+    c1 = {"config": names[1], "value": single_line["single_traj_ms"], "unit": "ms per optimizeSE2Traj call (one trajectory alone on the GPU, scaling + solve kernels)", "higher_is_better": False,
+          "lbfgs_iters": single_line["single_traj_lbfgs_iters"], "ms_per_lbfgs_iter": single_line["ms_per_lbfgs_iter"],
+          "cpu_baseline": {"value": min(ts) * 1e3, "unit": "ms per call", "cores": 1, "kind": "port", "sample": "the same goal, CPU oracle, best of 3", "us_per_objective_evaluation": cpu_eval_us}}
+    if pk:
+        h = pk["hill_x256"]
+        c1["penalty_kernel"] = {"workload": "the hill trajectory x 256, 20 evaluations per launch", "us_per_objective_evaluation": h["kernel_ms"] * 1e3 / h["evals_per_launch"],
+                                "roofline": {"bound": "hbm", "achieved": h["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h["frac"], "frac_moved": h["frac_moved"], "frac_a5_only": h["a5_only"]["frac"], "traffic": None}}
+    cfg.append(c1)
+    # ---- [2] desert (the reference's own cloud), batch of 256 random start / goal solves
+    try:
+        xyz = np.load(os.path.join(golden, "desert_xyz.npz"))["xyz"]
+        md = U.UnevenMap(device=m_hill.device)
+        md.build(xyz)
+        nx, ny = int(md.voxel_num[0]), int(md.voxel_num[1])
+        pd = scenes.random_problems(256, seed0=1000, occ_r2=md.occ_r2_buffer, grid=(nx, ny, md.xy_resolution, md.map_origin[0], md.map_origin[1]))
+        od = U.ALMTrajOpt(md)
+        od.upload(pd)
+        line, _ = solve_rate(torch, od, 256, 3)
+        ogd = O.OracleGrid()
+        ogd.set_cells(md.map_buffer)
+        line.update({"config": names[2], "workload": "uneven_map/maps/desert.pcd (fixture tests/golden/desert_xyz.npz), map built on the device, seeds 1000..1255, 3-10 m apart, run_hill.yaml parameters, full ALM solves",
+                     "map_build_ms": md.build_stats()["stages_ms"]["call"], "parity": first_eval_parity(U, O, md, ogd, pd, 8),
+                     "cpu_baseline": oracle_baseline(O, lambda p_: (ogd, p_), pd, 6.0, "the same batch")})
+        cfg.append(line)
+        del od, md
+    except Exception as e:
+        cfg.append({"config": names[2], "error": repr(e)})
+    # ---- [3] volcano: the SE(2) grid plane-fit build.  One GPU here; the 8-GPU x-slab exchange is played by 8 maps on this device (bit-identical grid required)
+    try:
+        xyz = np.load(os.path.join(golden, "vocano_xyz.npz"))["xyz"]
+        prm = dict(max_rho=0.08)                      # run_vocano.yaml differs from run_hill.yaml in max_rho only
+        mv = U.UnevenMap(prm, device=m_hill.device)
+        mv.build(xyz, download=False)
+        tb = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            mv.build(xyz, download=False)
+            tb.append(time.perf_counter() - t0)
+        st = mv.build_stats()
+        mv.download()
+        cells = st["cell_iters"]
+        # SURVEY.md 8d: ~87 candidate points x 12 B + 32 B out per cell-iteration at this density
+        by = cells * (87 * 12 + 32)
+        world = 8
+        maps = [U.UnevenMap(prm, device=m_hill.device) for _ in range(world)]
+        U.UnevenMap.build_multi(maps, xyz, download=False)
+        t0 = time.perf_counter()
+        stages = U.UnevenMap.build_multi(maps, xyz, download=False)
+        multi_s = time.perf_counter() - t0
+        same = True
+        for k_ in (0, world - 1):
+            maps[k_].download()
+            same = same and bool(np.array_equal(maps[k_].map_buffer, mv.map_buffer) and np.array_equal(maps[k_].occ_buffer, mv.occ_buffer))
+        del maps
+        # CPU baseline: the oracle's constructMap on two x-rows of the same cloud, projected to the 200 rows of the grid
+        ob = O.OracleMapBuilder(xyz=xyz)
+        ogv = O.OracleGrid()
+        rows = 2
+        t0 = time.perf_counter()
+        ob.construct(ogv, map_params=dict(mv.params), x0=100, x1=100 + rows, do_occ=False)
+        crow = time.perf_counter() - t0
+        co, _ = ogv.get_cells()
+        sl = slice(100 * int(mv.voxel_num[1]) * int(mv.voxel_num[2]), (100 + rows) * int(mv.voxel_num[1]) * int(mv.voxel_num[2]))
+        dcell = np.abs(mv.map_buffer.reshape(-1, 4)[sl] - co[sl]).max(axis=1)
+        cfg.append({"config": names[3], "value": min(tb) * 1e3, "unit": "ms per uph_map_build call (200 x 200 x 64 cells x 2 iterations, one GPU: upload, crop + voxel, bucketing, plane fits, commit)", "higher_is_better": False,
+                    "workload": "uneven_map/maps/vocano.pcd (fixture tests/golden/vocano_xyz.npz), run_vocano.yaml", "kernel_ms": st["kernel_ms"], "stages_ms": st["stages_ms"], "cell_iterations": cells,
+                    "M_cell_iterations_per_s": cells / (st["kernel_ms"] * 1e-3) / 1e6,
+                    "roofline": {"bound": "hbm", "achieved": by / (st["kernel_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (st["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "algorithmic_bytes_per_launch": by, "note": "algorithmic neighbourhood bytes (SURVEY.md 8d: 1.08 KB per cell-iteration); the kernel stages each (x, y) column's disc once in LDS and is bound by the arithmetic of the fits"},
+                    "world_of_8_on_one_device": {"slabs": world, "call_ms": multi_s * 1e3, "fit_ms": stages["fit_ms"], "exchange_ms": stages["exchange_ms"], "commit_ms": stages["commit_ms"], "via_rccl": stages["via_rccl"],
+                                                 "grid_bit_identical_to_the_single_build": same,
+                                                 "note": "uph_map_build_multi with 8 maps on this one device: the x-slab rule, the slab exchange (device-to-device copies -- RCCL refuses one device twice) and the commit of an 8-GPU build; the 8-device run itself is the driver's"},
+                    "parity": {"cells_compared": int(dcell.size), "max_abs_diff_vs_oracle": float(dcell.max()), "frac_within_1e-9": float((dcell < 1e-9).mean()), "ok": bool((dcell < 1e-9).mean() >= 0.999)},
+                    "cpu_baseline": {"value": crow / rows * int(mv.voxel_num[0]) * 1e3, "unit": "ms per build (projected)", "cores": 1, "kind": "port", "sample": "the oracle's constructMap on x-rows 100..%d of the same cloud (%.2f s), projected to %d rows" % (100 + rows - 1, crow, int(mv.voxel_num[0]))}})
+        if not same:
+            raise SystemExit("bench.py: the world-of-8 map build differs from the single build")
+        del mv
+    except SystemExit:
+        raise
+    except Exception as e:
+        cfg.append({"config": names[3], "error": repr(e)})
+    # ---- [4] 1 km^2 analytic fractal terrain in fp32 cells, batch of 4096 local goals: fp64 arithmetic and fp32 sample arithmetic
+    try:
+        from uneven_planner_amd.uneven_map import km2_map, km2_problems
+        t0 = time.perf_counter()
+        mk = km2_map(1000.0, 0, 1, m_hill.device)
+        fill_s = time.perf_counter() - t0
+        pk_ = km2_problems(mk, 1000.0, 4096, 0, 0, 1)
+        bps = 24 * 4 + 23 * 8                      # the gather reads fp32 cells; duals, scales, residuals, coefficients stay fp64
+        ok_ = U.ALMTrajOpt(mk)
+        ok_.upload(pk_)
+        l64, o64 = solve_rate(torch, ok_, 4096, 3, bps)
+        del ok_
+        o32 = U.ALMTrajOpt(mk)
+        o32.set_sample_precision(32)
+        o32.upload(pk_)
+        l32, _ = solve_rate(torch, o32, 4096, 3, bps)
+        del o32
+        nsamp = 12
+        cb = oracle_baseline(O, lambda p_: O.window_oracle(mk, p_)[:2], pk_[:nsamp], 8.0, "the same batch, each on the window of cells around it")
+        rel = []
+        for p_, d_ in zip(pk_[:nsamp], o64[:nsamp]):
+            g_, q_, sh = O.window_oracle(mk, p_)
+            r_ = O.OracleALM(g_).optimize(q_)
+            xo = np.array(r_["x"], dtype=np.float64).copy()
+            nin = np.asarray(p_["inner_xy"]).reshape(2, -1).shape[1]
+            xo[1:1 + 2 * nin:2] += sh[0]; xo[2:2 + 2 * nin:2] += sh[1]
+            rel.append((float(np.abs(d_["x"] - xo).max() / max(1e-300, np.abs(xo).max())), r_["lbfgs_iters"], int(d_["ret"] == r_["ret"])))
+        l64.update({"config": names[4], "workload": "analytic fBm terrain 1000 m x 1000 m at 0.25 m x 64 yaw bins = 1.02e9 fp32 cells (16.4 GB, filled on the device in %.1f s), 4096 local goals 4-14 m apart, "
+                                                    "each solved in its own local frame, fp64 arithmetic; one GPU here (the batch splits over the ranks for N > 1: bench.py --workload km2 --gpus N)" % fill_s,
+                    "dtype": "fp32 cell storage, f64 arithmetic", "map_fill_s": fill_s,
+                    "fp32_sample_arithmetic": {k_: l32[k_] for k_ in ("value", "unit", "ms_per_step", "converged_frac", "roofline")},
+                    "parity": dict(first_eval_parity(U, O, mk, None, pk_, 6, window=True), final_waypoints_le_1e4=float(np.mean([r_[0] <= 1e-4 for r_ in rel])), same_ret=float(np.mean([r_[2] for r_ in rel])),
+                                   final_sample=len(rel), note="final way-points of full solves against the window oracle: the optimiser is chaotic, the fraction decays with the oracle's iteration count (DESIGN.md 6)"),
+                    "cpu_baseline": cb})
+        cfg.append(l64)
+        del mk
+    except Exception as e:
+        cfg.append({"config": names[4], "error": repr(e)})
+    return {"seconds": time.perf_counter() - t_all, "entries": cfg}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,6 +484,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256, help="problems solved by the CPU oracle for cpu_baseline (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the penalty-kernel and small-batch measurements (profiling runs)")
+    ap.add_argument("--extras-multi", action="store_true", help="run rank 0's single-GPU extras (penalty kernel, small batches, front end ...) even when N > 1 (default: N = 1 only)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config block (BASELINE.json configs[0..4]: desert B = 256, volcano map build, km^2 B = 4096 fp64 / fp32 ...)")
     ap.add_argument("--workload", choices=("hill", "km2"), default="hill",
                     help="hill: the BASELINE metric's scene (default).  km2: configs[4] -- analytic 1 km^2 fractal terrain in fp32 cells, --batch (default 4096) "
                          "local-goal solves in total, split over the ranks (strong scaling)")
@@ -238,16 +521,34 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d -- the launcher's world size is what runs and what n_gpus reports\n" % (args.gpus, world))
+        # N copies of an N = 1 run (or an N-rank job reported as something else) must not pass for a scaling point
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world and the flag disagree" % (args.gpus, world))
     import torch
     import torch.distributed as dist
     if torch.cuda.device_count() < max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
         raise SystemExit("bench.py: %d ranks on this node but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     distributed = world > 1 or os.environ.get("UPH_FORCE_DIST") == "1"      # the env knob exercises the RCCL path with one rank
+    selftest = None
     if distributed:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        with Stage("rendezvous + RCCL communicator", 240, rank):
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: RCCL world of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+        # collective self-test before anything is measured: an all-gather of the rank ids and a sum with known answers over the communicator the run will use
+        with Stage("RCCL self-test", 120, rank) as stg:
+            mine = torch.full((1024,), float(rank), dtype=torch.float64, device="cuda")
+            allr = torch.empty(1024 * world, dtype=torch.float64, device="cuda")
+            dist.all_gather_into_tensor(allr, mine)
+            tot = mine.clone()
+            dist.all_reduce(tot)
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(allr.view(world, 1024)[:, 0].cpu(), torch.arange(world, dtype=torch.float64))) and float(tot[0].item()) == world * (world - 1) / 2.0
+        selftest = {"ok": ok, "world": dist.get_world_size(), "ms": stg.elapsed * 1e3, "what": "all_gather_into_tensor of the rank ids + all_reduce(sum) on the run's own communicator"}
+        if not ok:
+            raise SystemExit("bench.py: rank %d: the RCCL self-test returned wrong data" % rank)
     device = local_rank if distributed else 0
     torch.cuda.set_device(device)
 
@@ -256,6 +557,8 @@ def main():
 
     # ---- map on the device (not timed).  N > 1: x-slabs + one RCCL all-gather
     gather = lambda full, slab: dist.all_gather_into_tensor(full, slab)
+    stg_map = Stage("map build (+ slab all-gather)", 900 if km2 else 300, rank)
+    stg_map.__enter__()
     t0 = time.time()
     if km2:
         # configs[4]: analytic fractal terrain, fp32 cells (16 bytes per cell; 1 km^2 at 0.25 m x 64 yaw bins = 16.4 GB, replicated per GPU,
@@ -277,7 +580,22 @@ def main():
             m.download()                    # host copies of map_buffer / c_buffer / occupancy for the untouched host consumers: 105 MB into fresh numpy arrays
             map_download_s = time.time() - td
     map_build_s = time.time() - t0
+    stg_map.__exit__(None, None, None)
     map_stats = m.build_stats()
+    # every rank must hold the SAME grid before anything is solved on it: a hash of the host copy of the gathered cells, compared over the ranks
+    map_hash, map_hash_same = None, None
+    if not km2:
+        import hashlib
+        map_hash = hashlib.sha1(np.ascontiguousarray(m.map_buffer).tobytes()).hexdigest()[:15]
+        if distributed:
+            with Stage("map hash exchange", 120, rank):
+                hv = torch.tensor([int(map_hash, 16)], dtype=torch.int64, device="cuda")
+                hall = torch.empty(world, dtype=torch.int64, device="cuda")
+                dist.all_gather_into_tensor(hall, hv)
+                torch.cuda.synchronize()
+            map_hash_same = bool((hall == hall[0]).all().item())
+            if not map_hash_same:
+                raise SystemExit("bench.py: rank %d: the gathered map differs between ranks (%s)" % (rank, [hex(int(v)) for v in hall.tolist()]))
 
     # ---- problems, free cells only: config-3 protocol on the hill map; local goals (4..14 m) over the whole square for km2
     nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
@@ -303,9 +621,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        opt.set_rho(1.0)
-        opt.solve()
+    with Stage("warm-up (%d steps)" % args.warmup, 120 + 10 * args.warmup, rank):
+        for _ in range(args.warmup):
+            opt.set_rho(1.0)
+            opt.solve()
     # single-trajectory latency on the hill problem of configs[0]/[1] (not part of the timed region)
     single = U.ALMTrajOpt(m)
     single.upload([probs[0] if km2 else scenes.hill_problem()])
@@ -317,7 +636,7 @@ def main():
     single_iters = sst["lbfgs_iters"]
     del single
     extras = {}
-    if rank == 0 and not args.no_extras and not km2:
+    if rank == 0 and not args.no_extras and not km2 and (world == 1 or args.extras_multi):      # N > 1: the other ranks would sit at the barrier for the ~50 s these take
         # BASELINE configs[1]: the penalty kernel alone (uph_eval_batch: `repeat` objective+gradient evaluations per trajectory inside
         # one launch), on the hill trajectory x 256 and on the whole batch; algorithmic bytes = samples x 376 B
         R = 20
@@ -486,16 +805,17 @@ def main():
     opt.upload(probs)
 
     kernel_ms, prepare_ms, evals, sample_evals, iters, hist_bytes = [], [], 0, 0, 0, 0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        opt.set_rho(1.0)       # every step does identical work (rho would otherwise persist across solves, Q7)
-        opt.solve()
-        st = opt.stats()
-        kernel_ms.append(st["kernel_ms"]); prepare_ms.append(st["prepare_ms"])
-        evals += st["evals"]; sample_evals += st["sample_evals"]; iters += st["lbfgs_iters"]; hist_bytes += st["hist_bytes"]
-    barrier()
-    dt = time.perf_counter() - t0
+    with Stage("timed region (%d steps)" % args.steps, 60 + 10 * args.steps, rank):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            opt.set_rho(1.0)       # every step does identical work (rho would otherwise persist across solves, Q7)
+            opt.solve()
+            st = opt.stats()
+            kernel_ms.append(st["kernel_ms"]); prepare_ms.append(st["prepare_ms"])
+            evals += st["evals"]; sample_evals += st["sample_evals"]; iters += st["lbfgs_iters"]; hist_bytes += st["hist_bytes"]
+        barrier()
+        dt = time.perf_counter() - t0
     per_rank_ms = [dt / args.steps * 1e3]
     if distributed:
         mine = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -577,7 +897,8 @@ def main():
                                     "full ALM solves per GPU (configs[1] scene, configs[2] start/goal protocol), run_hill.yaml params" % args.batch),
                        "batch_per_gpu": args.batch, "grid": [nx, ny, int(m.voxel_num[2])], "launcher": "self-spawned ranks" if os.environ.get("UPH_BENCH_SPAWNED") == "1" else ("torch.distributed.run" if distributed else "single process"),
                        "rccl_world": dist.get_world_size() if distributed else 1, "parallelism": ("dp%d" % world) + (" (grid tiled by x-slab owner + 20 m halo)" if km2 and m.tile is not None else "")},
-            "per_rank_ms_per_step": per_rank_ms,
+            "per_rank_ms_per_step": per_rank_ms, "per_rank_spread": (max(per_rank_ms) - min(per_rank_ms)) / max(per_rank_ms),
+            "rccl_selftest": selftest, "map_hash": map_hash, "map_hash_identical_on_all_ranks": map_hash_same,
             "ms_per_lbfgs_iter": single_ms_per_iter,       # single hill trajectory alone on the GPU (configs[1]): solve kernel ms / its L-BFGS iterations
             "single_traj_ms": single_ms, "single_traj_lbfgs_iters": single_iters,      # (the solve is chaotic: a rounding-level change of the arithmetic moves this ONE problem's iteration count -- 216 / 253 in round 5 -- read ms_per_lbfgs_iter for the kernel)
             "batch_lbfgs_iters_per_s": iters / dt,
@@ -612,6 +933,9 @@ def main():
                                                                 "frac_a5_only: calConstrainCostGrad alone (uph_penalty_batch, uph_solver_kernel<128,2,8>: samples + scatter, residuals stored by every call) at 376 B, all of them moved",
                                                  "target": 0.70}
         res.update(extras)
+        if world == 1 and not km2 and not args.no_configs and not args.no_extras and not args.no_cpu:
+            # every BASELINE.json config in this one line (outside the timed region; N = 1 only -- for N > 1 the other ranks would wait at the barrier)
+            res["configs"] = measure_configs(args, torch, U, scenes, m, res, extras.get("penalty_kernel"))
         if pipelined:
             res["pipelined"] = pipelined
         if world == 1 and not args.no_cpu and args.cpu_sample > 0:

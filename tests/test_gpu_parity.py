@@ -122,8 +122,8 @@ def test_penalty_kernel_alone_matches_the_oracles_calConstrainCostGrad(dev, orac
         assert abs(d["gdTxy_sum"] - gtx.sum()) / max(1e-300, np.abs(gtx).sum()) < 1e-9
         assert abs(d["gdTyaw_sum"] - gty.sum()) / max(1e-300, np.abs(gty).sum()) < 1e-9
         assert rel(st["hx"], out[i]["hx"]) < 1e-9 and rel(st["gx"], out[i]["gx"]) < 1e-9
-        # the repeated, store-free form is the same function: identical bits
-        assert many[i]["cost"] == d["cost"] and np.array_equal(many[i]["gdCxy"], d["gdCxy"]) and np.array_equal(many[i]["gdCyaw"], d["gdCyaw"])
+        # the repeated, store-free form is the same function (another instantiation of the sample code: the compiler contracts it differently, rounding level)
+        assert abs(many[i]["cost"] - d["cost"]) / abs(d["cost"]) < 1e-12 and rel(d["gdCxy"], many[i]["gdCxy"]) < 1e-12 and rel(d["gdCyaw"], many[i]["gdCyaw"]) < 1e-12
 
 
 def test_init_scaling_matches_oracle(dev, oracle, oracle_grid, hill_problem, small_problems):

@@ -20,4 +20,15 @@ print(json.dumps(r["roofline"]["penalty_kernel"])[:1500])
 print(json.dumps(r["penalty_kernel"])[:2500])
 PY
 ;;
+2)
+# register diet of the sample code (pinned kinematic sums, late dual loads) at two and three waves per SIMD: penalty kernel + solve on the bench batch and on short problems
+OUT=gpurun_out/r06b; mkdir -p $OUT
+for v in default diet2 diet3 diet3e default diet3; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  echo "== $v"
+  timeout 400 python tools/ab_eval.py 16384 5.5 2>&1 | tail -3
+done 2>&1 | tee $OUT/ab.txt
+unset UNEVENHIP_LIB
+timeout 900 python -m pytest tests/test_gpu_map.py tests/test_gpu_parity.py -m gpu -q 2>&1 | tail -5 | tee $OUT/tests.txt
+;;
 esac

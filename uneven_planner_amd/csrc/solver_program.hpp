@@ -362,6 +362,7 @@ struct Solver {
                 const R cv = c[k * 2 + dd];
                 a += cv * S_.b0[k]; b += cv * S_.b1[k]; cc += cv * S_.b2[k]; e += cv * S_.b3[k];
             }
+            if (UPH_DIET && !WITH_GRADS) { pinv(a); pinv(b); pinv(cc); pinv(e); }      // formed HERE: the coefficients die before the gather
             S_.pos[dd] = a; S_.vel[dd] = b; S_.acc[dd] = cc; S_.jer[dd] = e;
         }
         const R now_time = s1 + bt[i];                             // :748-753
@@ -379,6 +380,7 @@ struct Solver {
         R yaw = R(0.0), dyaw = R(0.0), d2yaw = R(0.0);                            // :762-764
 #pragma unroll
         for (int k = 0; k < 6; k++) { const R cv = cy[k]; yaw += cv * S_.y0[k]; dyaw += cv * S_.y1[k]; d2yaw += cv * S_.y2[k]; }
+        if (UPH_DIET && !WITH_GRADS) { pinv(yaw); pinv(dyaw); pinv(d2yaw); }
         S_.yaw = yaw; S_.dyaw = dyaw; S_.d2yaw = d2yaw;
         const R yawn = normSO2(yaw);                               // :767-770
         sincosFast(yaw, S_.syaw, S_.cyaw);                              // one argument reduction for both
@@ -415,7 +417,9 @@ struct Solver {
         rec[0 * CHP + slot] = gp_[0]; rec[1 * CHP + slot] = gp_[1];
         rec[2 * CHP + slot] = gv_[0]; rec[3 * CHP + slot] = gv_[1];
         rec[4 * CHP + slot] = ga_[0]; rec[5 * CHP + slot] = ga_[1];
-        const R u1 = k.u, u2 = u1 * u1, u3 = u2 * u1, u4 = u2 * u2, u5 = u4 * u1;
+        R u1 = k.u;
+        if (UPH_DIET) pinv(u1);                          // (the powers are REBUILT here: not carried from kin() across the gather and the penalties)
+        const R u2 = u1 * u1, u3 = u2 * u1, u4 = u2 * u2, u5 = u4 * u1;
         rec[6 * CHP + slot] = gyaw;
         rec[7 * CHP + slot] = (u1 * gyaw + gdyaw);
         rec[8 * CHP + slot] = (u2 * gyaw + 2.0 * u1 * gdyaw);
@@ -425,7 +429,9 @@ struct Solver {
         rtag[slot] = k.yaw_idx;
         if (i == 0) {                                    // the powers behind beta0/1/2 of alm_traj_opt.cpp:738-740 at s1(j) (rebuilt from s1: not kept live across the sample)
             double* w = wtab + 6 * j;
-            const R s1 = k.s1, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+            R s1 = k.s1;
+            if (UPH_DIET) pinv(s1);
+            const R s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
             w[0] = 1.0; w[1] = s1; w[2] = s2; w[3] = s3; w[4] = s4; w[5] = s5;
         }
     }

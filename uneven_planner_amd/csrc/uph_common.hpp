@@ -187,6 +187,23 @@ struct BatchDev {
     const double* thomas;   // block-LU factors of the MINCO knot system, THOMAS_DOUBLES (minco_op_host.hpp); shared by every trajectory, copied to LDS per workgroup
 };
 
+// Register diet of the sample code (UPH_DIET, the three-waves-per-SIMD build): pinv(x) is an empty asm that "uses and redefines" x -- the value has to exist in a
+// register AT THIS POINT of the program, so whatever it was computed from can die here instead of being carried to a later, cheaper-looking place
+// (the scheduler otherwise sinks e.g. the acceleration / jerk sums to their single late use and keeps the piece's twelve coefficients alive across the whole
+// terrain gather: tools/isa_pressure.py).  Also stops common-subexpression elimination across it: a value recomputed from a pinned input is really recomputed.
+#if defined(__HIP_DEVICE_COMPILE__)
+UPH_HD void pinv(double& v) { asm volatile("" : "+v"(v)); }
+UPH_HD void pinv(float& v) { asm volatile("" : "+v"(v)); }
+UPH_HD void pinv(int& v) { asm volatile("" : "+v"(v)); }
+#else
+UPH_HD void pinv(double&) {}
+UPH_HD void pinv(float&) {}
+UPH_HD void pinv(int&) {}
+#endif
+#ifndef UPH_DIET
+#define UPH_DIET 0
+#endif
+
 UPH_HD double dmax(double a, double b) { return a > b ? a : b; }
 UPH_HD double dmin(double a, double b) { return a < b ? a : b; }
 
@@ -301,6 +318,7 @@ struct f32r {
     UPH_HD operator double() const { return (double)v; }
 };
 UPH_HD f32r mkf(float f) { return f32r(f, 0); }
+UPH_HD void pinv(f32r& a) { pinv(a.v); }
 #define UPH_F32_BINOP(op)                                                                   \
     UPH_HD f32r operator op(f32r a, f32r b) { return mkf(a.v op b.v); }                       \
     UPH_HD f32r operator op(f32r a, double b) { return mkf(a.v op (float)b); }                \
