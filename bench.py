@@ -41,13 +41,16 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
+PMC_FILE = "pmc_traffic.json"      # (--workload astar: pmc_traffic_astar.json -- its own committed counter pass)
+
+
 def pmc_counters(batch):
-    """the committed counter pass (profiles/pmc_traffic.json, written by tools/profile.sh) if it describes THIS kernel and batch size, else (None, why)"""
+    """the committed counter pass (profiles/pmc_traffic*.json, written by tools/profile.sh) if it describes THIS kernel, workload and batch size, else (None, why)"""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             t = json.load(f)
     except Exception:
-        return None, "no profiles/pmc_traffic.json"
+        return None, "no profiles/" + PMC_FILE
     if int(t.get("batch", -1)) != int(batch):
         return None, "the committed counter pass (%s) is for B = %s, not for this batch size" % (t.get("tag"), t.get("batch"))
     if t.get("kernel_src_sha") != kernel_sources_sha():
@@ -262,6 +265,25 @@ def single_process_dry_run(args):
     line["dry_run"] = {"slabs": [[int(x0[g]), int(x1[g])] for g in range(N)], "rows_per_slab": int(per.value), "all_gather_in_place": bool(inpl.value),
                        "seed0_per_device": [1000 + g * B for g in range(N)]}
     print(json.dumps(line), flush=True)
+
+
+def astar_batch(U, scenes, m, gridinfo, want, seed0):
+    """The batch the goal -> trajectory chain produces (the reference's rcvWpsCallBack, plan_manager.cpp:55-134): KinoAstar::plan on the device for random hill
+    goals (config-3 protocol, seeds from seed0), PlanManager's resampling stage (uph_resample_batch) on every path found; exactly `want` problems (goals are
+    drawn until that many searches have succeeded; ~4 % of the random goals have no path and are dropped as the reference drops them)."""
+    from uneven_planner_amd import resample as RS
+    ka = U.KinoAstar(m, slots=4096)
+    probs, goals, found, t_search = [], 0, 0, 0.0
+    while len(probs) < want:
+        nq = max(256, int((want - len(probs)) / 0.94) + 64)
+        S_, G_ = scenes.random_queries(nq, seed0=seed0 + goals, occ_r2=m.occ_r2_buffer, grid=gridinfo)
+        sr = ka.plan_batch(S_, G_, path_cap=768)
+        t_search += ka.stats()["kernel_ms"] * 1e-3
+        paths = [q_["path"] for q_ in sr if q_["status"] == 0 and q_["n_path"] <= 768]
+        goals += nq; found += len(paths)
+        probs += RS.resample_batch(paths)
+    del ka
+    return probs[:want], {"goals_drawn": goals, "paths_found": found, "search_kernel_s": t_search}
 
 
 def solve_rate(torch, opt, B, K, bytes_per_sample=BYTES_PER_SAMPLE_EVAL):
@@ -486,9 +508,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the penalty-kernel and small-batch measurements (profiling runs)")
     ap.add_argument("--extras-multi", action="store_true", help="run rank 0's single-GPU extras (penalty kernel, small batches, front end ...) even when N > 1 (default: N = 1 only)")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config block (BASELINE.json configs[0..4]: desert B = 256, volcano map build, km^2 B = 4096 fp64 / fp32 ...)")
-    ap.add_argument("--workload", choices=("hill", "km2"), default="hill",
-                    help="hill: the BASELINE metric's scene (default).  km2: configs[4] -- analytic 1 km^2 fractal terrain in fp32 cells, --batch (default 4096) "
-                         "local-goal solves in total, split over the ranks (strong scaling)")
+    ap.add_argument("--workload", choices=("hill", "astar", "km2"), default="hill",
+                    help="hill: the BASELINE metric's scene, Hermite stand-in initial paths (default).  astar: the same scene and goal protocol with the initial paths the "
+                         "reference's own chain produces -- KinoAstar::plan on the device + PlanManager's resampling -- instead of the stand-in (--batch solves per GPU, default 16384).  "
+                         "km2: configs[4] -- analytic 1 km^2 fractal terrain in fp32 cells, --batch (default 4096) local-goal solves in total, split over the ranks (strong scaling)")
     ap.add_argument("--map-size", type=float, default=1000.0, help="km2 workload: side of the square map [m]")
     ap.add_argument("--tiled", action="store_true", help="km2 workload, N > 1: every rank holds only its x-slab of the grid plus a 20 m halo and solves the problems that "
                                                          "start in its slab (owner routing, SURVEY.md 8e row 3) instead of replicating the grid")
@@ -513,6 +536,10 @@ def main():
             return single_process_dry_run(args)
         return single_process(args)
     km2 = args.workload == "km2"
+    astar_wl = args.workload == "astar"
+    if astar_wl:
+        global PMC_FILE
+        PMC_FILE = "pmc_traffic_astar.json"
     map_device_s = map_device_warm_s = map_download_s = None
     if not args.batch:
         args.batch = 4096 if km2 else 16384
@@ -607,6 +634,9 @@ def main():
             raise SystemExit("km2: batch of %d cannot be split over %d ranks" % (total_batch, world))
         from uneven_planner_amd.uneven_map import km2_problems
         probs = km2_problems(m, args.map_size, args.batch, lo, rank, world)
+    elif astar_wl:
+        with Stage("front end: searches + resampling for the A*-seeded batch", 300, rank):
+            probs, astar_meta = astar_batch(U, scenes, m, gridinfo, args.batch, 1000 + rank * 2 * args.batch)
     else:
         probs = scenes.random_problems(args.batch, seed0=1000 + rank * args.batch, occ_r2=m.occ_r2_buffer, grid=gridinfo)
     opt = U.ALMTrajOpt(m)
@@ -636,7 +666,7 @@ def main():
     single_iters = sst["lbfgs_iters"]
     del single
     extras = {}
-    if rank == 0 and not args.no_extras and not km2 and (world == 1 or args.extras_multi):      # N > 1: the other ranks would sit at the barrier for the ~50 s these take
+    if rank == 0 and not args.no_extras and not km2 and not astar_wl and (world == 1 or args.extras_multi):      # N > 1: the other ranks would sit at the barrier for the ~50 s these take
         # BASELINE configs[1]: the penalty kernel alone (uph_eval_batch: `repeat` objective+gradient evaluations per trajectory inside
         # one launch), on the hill trajectory x 256 and on the whole batch; algorithmic bytes = samples x 376 B
         R = 20
@@ -893,8 +923,11 @@ def main():
             "vs_baseline": None, "dtype": "f32 samples / f64 solver" if args.fp32 else "f64", "data": "synthetic",
             "config": {"workload": ("configs[4]: analytic fractal terrain %.0f m x %.0f m (fBm H 0.8, seed 7), fp32 cell storage with fp64 arithmetic, one batch of %d "
                                     "local-goal (4-14 m) full ALM solves split over the GPUs, run_hill.yaml params" % (args.map_size, args.map_size, total_batch)) if km2 else
-                                   ("hill scene (synthetic hill cloud, map built on device), batch of %d random start/goal "
-                                    "full ALM solves per GPU (configs[1] scene, configs[2] start/goal protocol), run_hill.yaml params" % args.batch),
+                                   (("hill scene (synthetic hill cloud, map built on device), A*-seeded batch: %d problems per GPU = random start/goal pairs (configs[2] protocol) whose "
+                                     "KinoAstar::plan search (device) found a path, resampled by PlanManager's stage (piece_len 0.3, yaw_piece_times 2, mean_vel 0.5 ...), "
+                                     "full ALM solves, run_hill.yaml params" % args.batch) if astar_wl else
+                                    ("hill scene (synthetic hill cloud, map built on device), batch of %d random start/goal "
+                                     "full ALM solves per GPU (configs[1] scene, configs[2] start/goal protocol), run_hill.yaml params" % args.batch)),
                        "batch_per_gpu": args.batch, "grid": [nx, ny, int(m.voxel_num[2])], "launcher": "self-spawned ranks" if os.environ.get("UPH_BENCH_SPAWNED") == "1" else ("torch.distributed.run" if distributed else "single process"),
                        "rccl_world": dist.get_world_size() if distributed else 1, "parallelism": ("dp%d" % world) + (" (grid tiled by x-slab owner + 20 m halo)" if km2 and m.tile is not None else "")},
             "per_rank_ms_per_step": per_rank_ms, "per_rank_spread": (max(per_rank_ms) - min(per_rank_ms)) / max(per_rank_ms),
@@ -916,6 +949,9 @@ def main():
                              pc.get("tag"), pc.get("git_head"), pc.get("kernel_src_sha"), pc.get("launch_ms", float("nan")))) if pc is not None else pc_why,
                          "kernel_src_sha": kernel_sources_sha()},
         }
+        if astar_wl:
+            res["metric"] = "MINCO traj-opts/sec (batch), A*-seeded inputs"
+            res["front_end"] = dict(astar_meta, mean_pieces=float(np.mean([s_["Nxy"] for s_ in opt._sizes])))
         res["converged_traj_opts_per_s"] = value * res["converged_frac"]      # solves that END converged (ret_code 0); the rest hit the ALM pass cap like the reference's
         fe_queries = extras.pop("_front_end_queries", None)
         astar = extras.pop("_astar", None)

@@ -1,19 +1,22 @@
-# usage: bash tools/profile.sh <tag>   (on the GPU box)  -> gpurun_out/prof_<tag>/ ; copy the summaries into profiles/<tag>_*
+# usage: [WL=astar] bash tools/profile.sh <tag>   (on the GPU box)  -> gpurun_out/prof_<tag>/ ; copy the summaries into profiles/<tag>_*
+# WL=astar: the same passes for `bench.py --workload astar` (its own pmc_traffic_astar.json; no calibration / penalty-kernel passes)
 # 1. bench line un-profiled  2. rocprofv3 --kernel-trace --stats of the same command (no counters)  3. separate --pmc passes (counters only)
 # 4. FETCH_SIZE / WRITE_SIZE calibration on known-byte microkernels (tools/micro/fetch_calib.hip)  5. penalty-kernel-only trace (configs[1])
 cd $GRAFT_REPO_ROOT
 TAG=${1:-r02}
+WLF=""; [ "${WL:-hill}" = astar ] && WLF="--workload astar"
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 make -C oracle -s 2>&1 | tail -2
-python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
+python bench.py $WLF --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; echo
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-extras > $OUT/bench_profiled.json 2> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $GRAFT_REPO_ROOT/bench.py $WLF --steps 3 --warmup 1 --no-cpu --no-extras > $OUT/bench_profiled.json 2> $OUT/rocprof.err
 for f in $(find $OUT/kt -name "*kernel_stats*.csv"); do cp $f $OUT/kernel_stats.csv; done
 head -6 $OUT/kernel_stats.csv | cut -c1-200
-# penalty kernel alone: 3 launches of uph_eval_batch(repeat = 20) on the batch
+if [ -z "$WLF" ]; then
+# penalty kernel alone: 3 launches of uph_eval_batch(repeat = 20) on the batch, then 3 of uph_penalty_batch (A5 alone)
 cat > /tmp/evalonly.py <<'PY'
 import sys, os
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
@@ -21,16 +24,19 @@ import uneven_planner_amd as U
 from uneven_planner_amd import scenes
 m = U.UnevenMap(); m.build(scenes.make_hill_cloud())
 nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
-probs = scenes.random_problems(8192, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
+probs = scenes.random_problems(16384, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
 opt = U.ALMTrajOpt(m); opt.upload(probs); opt.init_scaling_batch()
 for _ in range(3): opt.eval_batch(None, repeat=20)
 print("eval kernel ms", opt.stats()["kernel_ms"])
+for _ in range(3): opt.penalty_batch(repeat=20, store_residuals=True)
+print("A5-only kernel ms", opt.stats()["kernel_ms"])
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ev -o ev -- python /tmp/evalonly.py > $OUT/eval_only.txt 2> $OUT/eval_only.err
 for f in $(find $OUT/ev -name "*kernel_stats*.csv"); do cp $f $OUT/eval_kernel_stats.csv; done
-grep "Li0EE\|, 0>" $OUT/eval_kernel_stats.csv | cut -c1-200
+grep "Li0EE\|, 0>\|Li8EE\|, 8>" $OUT/eval_kernel_stats.csv | cut -c1-200
+fi
 pmc() { name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-extras > $OUT/$name.json 2> $OUT/$name.err
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $GRAFT_REPO_ROOT/bench.py $WLF --steps 1 --warmup 0 --no-cpu --no-extras > $OUT/$name.json 2> $OUT/$name.err
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   python - "$f" "$OUT/pmc_summary.txt" <<'PY'
 import sys, csv, collections, re
@@ -53,7 +59,7 @@ pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ
 pmc mfma SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES
 # calibration: counted vs requested bytes on known patterns
 rm -f $OUT/fetch_calibration.txt
-for pat in gather8 rows16 stream16 stream8 write8; do
+[ -n "$WLF" ] || for pat in gather8 rows16 stream16 stream8 write8; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --output-format csv -d $OUT/cal_${pat}_$ctr -o c -- $GRAFT_REPO_ROOT/build/micro/fetch_calib $pat > $OUT/cal_$pat.txt 2>> $OUT/cal.err
     f=$(find $OUT/cal_${pat}_$ctr -name "*counter_collection.csv" | head -1)
@@ -68,7 +74,7 @@ print('%-9s %-10s counted %.6g KiB = %.6g bytes   requested %.6g bytes   counted
 PY
   done
 done
-cat $OUT/fetch_calibration.txt
+[ -n "$WLF" ] || cat $OUT/fetch_calibration.txt
 python - $OUT <<'PY'
 import sys, json
 out = sys.argv[1]
@@ -87,6 +93,6 @@ json.dump({'batch': B, 'tag': 'profiles/%s_pmc_summary.txt' % os.path.basename(o
            'sq_insts_valu_mfma_f64': vals.get('SQ_INSTS_VALU_MFMA_F64', 0.0), 'sq_insts_valu_mfma_mops_f64': vals.get('SQ_INSTS_VALU_MFMA_MOPS_F64', 0.0), 'sq_valu_mfma_busy_cycles': vals.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0),
            'launch_ms': line['roofline']['avg_launch_ms'], 'kernel_src_sha': bench.kernel_sources_sha(), 'git_head': head,
            'note': 'ALM/L-BFGS solve kernel (uph_solver_kernel<*,2,2>), one launch of bench.py --steps 1 --warmup 0 (default batch); rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; see <tag>_fetch_calibration.txt for counted/requested on known patterns'},
-          open(out + '/pmc_traffic.json', 'w'), indent=1)
+          open(out + ('/pmc_traffic_astar.json' if os.environ.get('WL') == 'astar' else '/pmc_traffic.json'), 'w'), indent=1)
 PY
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace*" -size +2M -delete; find $OUT -name "*counter_collection.csv" -size +2M -delete; find $OUT -name "*agent_info*" -delete

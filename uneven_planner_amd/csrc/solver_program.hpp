@@ -43,6 +43,10 @@ namespace uph {
 #ifndef UPH_PHASE_MASK
 #define UPH_PHASE_MASK 15
 #endif
+// columns of the knot operator fetched per batch in initScaling's row gathers (scalingGroup)
+#ifndef UPH_SCALING_WB
+#define UPH_SCALING_WB 8
+#endif
 #ifndef UPH_SC_XB
 #define UPH_SC_XB 9
 #endif
@@ -1046,10 +1050,10 @@ struct Solver {
         const auto WL = UPH_AS_GLOBAL(Wr_xy + (size_t)(inL ? 2 * (i - 1) : 0) * nbx);      // rows v_i, a_i
         const auto WR = UPH_AS_GLOBAL(Wr_xy + (size_t)(inR ? 2 * i : 0) * nbx);            // rows v_{i+1}, a_{i+1}
         const int pcL = knotCol(i, Nxy), pcR = knotCol(i + 1, Nxy);
-        for (int c0 = 3; c0 < Nxy + 2; c0 += 8) {
-            double w[4][8];
+        for (int c0 = 3; c0 < Nxy + 2; c0 += UPH_SCALING_WB) {
+            double w[4][UPH_SCALING_WB];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < UPH_SCALING_WB; u++) {
                 const int cc = c0 + u < Nxy + 2 ? c0 + u : Nxy + 1;
                 w[0][u] = WL[cc]; w[1][u] = WL[nbx + cc]; w[2][u] = WR[cc]; w[3][u] = WR[nbx + cc];
             }
@@ -1060,7 +1064,7 @@ struct Solver {
                 const double c20 = inR ? dvR[q][0] : 0.0, c21 = inR ? dvR[q][1] : 0.0, c30 = inR ? daR[q][0] : 0.0, c31 = inR ? daR[q][1] : 0.0;
                 double mq = mx[q];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < UPH_SCALING_WB; u++) {
                     const int col = c0 + u;
                     double a0 = (w[0][u] * c00 + w[1][u] * c10) + (w[2][u] * c20 + w[3][u] * c30);
                     double a1 = (w[0][u] * c01 + w[1][u] * c11) + (w[2][u] * c21 + w[3][u] * c31);
@@ -1102,10 +1106,10 @@ struct Solver {
         const auto VL = UPH_AS_GLOBAL(Wr_yaw + (size_t)(yL ? 2 * (m - 1) : 0) * nby);
         const auto VR = UPH_AS_GLOBAL(Wr_yaw + (size_t)(yR ? 2 * m : 0) * nby);
         const int qL = knotCol(m, Nyaw), qR = knotCol(m + 1, Nyaw);
-        for (int c0 = 3; c0 < Nyaw + 2; c0 += 8) {
-            double w[4][8];
+        for (int c0 = 3; c0 < Nyaw + 2; c0 += UPH_SCALING_WB) {
+            double w[4][UPH_SCALING_WB];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < UPH_SCALING_WB; u++) {
                 const int cc = c0 + u < Nyaw + 2 ? c0 + u : Nyaw + 1;
                 w[0][u] = VL[cc]; w[1][u] = VL[nby + cc]; w[2][u] = VR[cc]; w[3][u] = VR[nby + cc];
             }
@@ -1114,7 +1118,7 @@ struct Solver {
                 const double y0_ = yL ? yvL[q] : 0.0, y1_ = yL ? yaL[q] : 0.0, y2_ = yR ? yvR[q] : 0.0, y3_ = yR ? yaR[q] : 0.0;
                 double mq = mx[q];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < UPH_SCALING_WB; u++) {
                     const int col = c0 + u;
                     double a0 = (w[0][u] * y0_ + w[1][u] * y1_) + (w[2][u] * y2_ + w[3][u] * y3_);
                     if (col == qL) a0 += ypL[q];
