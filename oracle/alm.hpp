@@ -133,8 +133,13 @@ struct AlmTrajOpt {
         for (size_t i = 0; i < gPyaw.size(); i++) grad[dim_T + 2 * (piece_xy - 1) + i] = gPyaw[i];
         double tau_cost = p.rho_T * expC2(tau) * scale_fx;                        // :340-344
         double sx = 0, sy = 0;
+#if ORACLE_EIGEN_REDUX
+        sx = eigen_redux_linear((int)gdTxy.size(), [&](int i) { return gdTxy[i]; });      // gdTxy.sum(), alm_traj_opt.cpp:342-343
+        sy = eigen_redux_linear((int)gdTyaw.size(), [&](int i) { return gdTyaw[i]; });
+#else
         for (double v : gdTxy) sx += v;
         for (double v : gdTyaw) sy += v;
+#endif
         double grad_Tsum = p.rho_T * scale_fx + sx / piece_xy + sy / piece_yaw;
         grad[0] = grad_Tsum * getTtoTauGrad(tau);
         last_jerk_cost_term = jerk_cost; last_constrain_cost = constrain_cost; last_tau_cost = tau_cost;

@@ -5,12 +5,14 @@
 //   return codes             :135-184
 //   line_search_lewisoverton :276-389  (incl. the non-upstream early accept :327-330)
 //   lbfgs_optimize           :439-722
-// Vectors are std::vector<double>; Eigen reductions are summed left to right.
+// Vectors are std::vector<double>; Eigen reductions are summed left to right (or, -DORACLE_EIGEN_REDUX=1, in Eigen 3.3.7's own order: eigen_redux.hpp).
 #pragma once
 #include <algorithm>
 #include <cmath>
 #include <functional>
 #include <vector>
+
+#include "eigen_redux.hpp"
 
 namespace orc {
 
@@ -59,8 +61,15 @@ using Vec = std::vector<double>;
 using EvalFn = std::function<double(const Vec& x, Vec& g)>;
 using ProgressFn = std::function<int(const Vec& x, const Vec& g, double fx, double step, int k, int ls)>;
 
-inline double vdot(const Vec& a, const Vec& b) { double s = 0; for (size_t i = 0; i < a.size(); i++) s += a[i] * b[i]; return s; }
-inline double vdotp(const double* a, const double* b, int n) { double s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s; }
+// (default build: left to right; -DORACLE_EIGEN_REDUX=1: the association of Eigen 3.3.7's vectorised redux, eigen_redux.hpp)
+inline double vdotp(const double* a, const double* b, int n) {
+#if ORACLE_EIGEN_REDUX
+    return eigen_redux_linear(n, [&](int i) { return a[i] * b[i]; });
+#else
+    double s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s;
+#endif
+}
+inline double vdot(const Vec& a, const Vec& b) { return vdotp(a.data(), b.data(), (int)a.size()); }
 inline double vabsmax(const Vec& a) { double m = 0; for (double v : a) m = std::max(m, std::fabs(v)); return m; }
 
 struct LbfgsStats { int iters = 0; int evals = 0; };

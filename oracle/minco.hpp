@@ -13,6 +13,7 @@
 #include <cmath>
 #include <vector>
 #include "banded.hpp"
+#include "eigen_redux.hpp"
 
 namespace orc {
 
@@ -163,8 +164,12 @@ struct MinJerk {
                 B1[1 * D + d] = -120.0 * C(i * 6 + 5, d);
             }
             double s = 0.0;   // column-major traversal of the 6 x D product
+#if ORACLE_EIGEN_REDUX
+            s = eigen_redux_block(6, D, [&](int r, int d) { return B1[r * D + d] * adj[(6 * i + 3 + r) * D + d]; });
+#else
             for (int d = 0; d < D; d++)
                 for (int r = 0; r < 6; r++) s += B1[r * D + d] * adj[(6 * i + 3 + r) * D + d];
+#endif
             gdT[i] += s;
         }
         double B2[3 * 4];
@@ -176,8 +181,12 @@ struct MinJerk {
             B2[2 * D + d] = -(6.0 * C(6 * N - 3, d) + 24.0 * T1[N - 1] * C(6 * N - 2, d) + 60.0 * T2[N - 1] * C(6 * N - 1, d));
         }
         double s = 0.0;
+#if ORACLE_EIGEN_REDUX
+        s = eigen_redux_block(3, D, [&](int r, int d) { return B2[r * D + d] * adj[(6 * N - 3 + r) * D + d]; });
+#else
         for (int d = 0; d < D; d++)
             for (int r = 0; r < 3; r++) s += B2[r * D + d] * adj[(6 * N - 3 + r) * D + d];
+#endif
         gdT[N - 1] += s;
     }
 };

@@ -508,6 +508,18 @@ void orc_dubins_interpolate(const double* from3, const double* to3, double rho, 
 void orc_kino_state_transit(void* h, const double* state0, const double* ctrl2, double T, double* state1) { ((OrcKino*)h)->ka.stateTransit(state0, state1, ctrl2, T); }
 // The restated heap (KinoAstar::pushHeap / popHeap) against std::priority_queue itself on a random stream of pushes, pops and IN-PLACE
 // changes of queued keys (what kino_astar.cpp:218-229 does), NaN keys included: returns the number of pops that differed.
+// the dot product exactly as the L-BFGS restatement forms it: left to right in the default build, Eigen 3.3.7's redux order with -DORACLE_EIGEN_REDUX=1
+double orc_dot(const double* a, const double* b, int n) { return vdotp(a, b, n); }
+int orc_eigen_redux_enabled() { return ORACLE_EIGEN_REDUX; }
+double orc_block_sum(const double* e, int rows, int dim) {      // e[r * dim + d]: the 6 x Dim / 3 x Dim block reduction of calGradCTtoQT in this build's order
+#if ORACLE_EIGEN_REDUX
+    return eigen_redux_block(rows, dim, [&](int r, int d) { return e[r * dim + d]; });
+#else
+    double s = 0.0;
+    for (int d = 0; d < dim; d++) for (int r = 0; r < rows; r++) s += e[r * dim + d];
+    return s;
+#endif
+}
 int orc_heap_selfcheck(unsigned seed, int nops, int nan_every) {
     struct Cmp { const std::vector<KinoNode>* pool; bool operator()(int a, int b) const { return (*pool)[a].f_score > (*pool)[b].f_score; } };
     Grid g; g.init(1.0, 1.0, 0.05, 0.1);

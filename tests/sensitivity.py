@@ -42,10 +42,17 @@ class fma_session:
         return False
 
 
-def solve_with_fma_oracle(cells, probs, params=None, grid_kw=None, threads=1):
+def solve_with_eigen_order_oracle(cells, probs, params=None, grid_kw=None, threads=1):
+    """the oracle rebuilt with -DORACLE_EIGEN_REDUX=1: every dynamic-vector reduction of the L-BFGS (dot, squaredNorm, norm), the gdT sums and the fixed-size
+    block products of calGradCTtoQT summed in the order of Eigen 3.3.7's vectorised redux for SSE2 (oracle/eigen_redux.hpp) instead of left to right;
+    same compiler flags as the default oracle otherwise"""
+    return solve_with_fma_oracle(cells, probs, params, grid_kw, threads, flags=("-O3", "-DORACLE_EIGEN_REDUX=1"), tag="eig")
+
+
+def solve_with_fma_oracle(cells, probs, params=None, grid_kw=None, threads=1, flags=("-O3", "-march=native", "-ffp-contract=fast"), tag="fma"):
     from oracle import oracle_py as O
-    so = "/tmp/liboracle_fma_%d.so" % os.getpid()
-    subprocess.check_call(["g++", "-O3", "-march=native", "-ffp-contract=fast", "-std=c++17", "-fPIC", "-shared", "-o", so,
+    so = "/tmp/liboracle_%s_%d.so" % (tag, os.getpid())
+    subprocess.check_call(["g++"] + list(flags) + ["-std=c++17", "-fPIC", "-shared", "-o", so,
                            os.path.join(ROOT, "oracle", "oracle_capi.cpp")])
     saved = O._LIB
     O._LIB = None

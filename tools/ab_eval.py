@@ -13,8 +13,10 @@ m = U.UnevenMap()
 m.build(scenes.make_hill_cloud())
 nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
 grid = (nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1])
-for tag, probs in (("batch", scenes.random_problems(B, seed0=1000, occ_r2=m.occ_r2_buffer, grid=grid)),
-                   ("short", scenes.random_problems(B, seed0=1000, dmin=3.0, dmax=dmax, occ_r2=m.occ_r2_buffer, grid=grid))):
+sets = [("batch", scenes.random_problems(B, seed0=1000, occ_r2=m.occ_r2_buffer, grid=grid))]
+if dmax > 0:
+    sets.append(("short", scenes.random_problems(B, seed0=1000, dmin=3.0, dmax=dmax, occ_r2=m.occ_r2_buffer, grid=grid)))
+for tag, probs in sets:
     opt = U.ALMTrajOpt(m)
     opt.set_lanes(128)
     opt.upload(probs)
@@ -35,5 +37,8 @@ for tag, probs in (("batch", scenes.random_problems(B, seed0=1000, occ_r2=m.occ_
         opt.solve()
         st = opt.stats()
         sm.append(st["kernel_ms"])
+        pm = st["prepare_ms"]
     out = opt.download(full=False)
-    print(line + " | solve: %.2f ms (%.0f traj/s), evals %d, converged %.3f" % (min(sm), B / min(sm) * 1e3, st["evals"], np.mean([o["ret"] == 0 for o in out])), flush=True)
+    import hashlib
+    hx = hashlib.sha1(np.concatenate([o["x"] for o in out]).tobytes()).hexdigest()[:10]
+    print(line + " | solve: %.2f ms (%.0f traj/s), scaling %.2f ms, evals %d, converged %.3f, results %s" % (min(sm), B / min(sm) * 1e3, pm, st["evals"], np.mean([o["ret"] == 0 for o in out]), hx), flush=True)

@@ -61,4 +61,15 @@ print("dist1:", r["value"], r["rccl_selftest"], r["map_hash"], r["map_hash_ident
 PY
 timeout 300 python bench.py --gpus 1 --single-process --steps 2 --warmup 1 > $OUT/bench_sp1.json 2> $OUT/bench_sp1.err; echo "sp1 rc $?"; tail -c 600 $OUT/bench_sp1.json
 ;;
+4)
+# where the two waves of a workgroup land (SIMD ids), and the chain-running role dealt to alternating waves; scaling-kernel regrouping
+OUT=gpurun_out/r06d; mkdir -p $OUT
+./build/micro/wave_placement 4096 20000 2>&1 | tee $OUT/wave_placement.txt | tail -12
+for v in default flip1 flip9 flip10 flip16 sc3 default flip16; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  [ -z "${UNEVENHIP_LIB:-}" ] || [ -f "$UNEVENHIP_LIB" ] || continue
+  echo "== $v"
+  timeout 400 python tools/ab_eval.py 16384 0 2>&1 | tail -1
+done 2>&1 | tee $OUT/ab.txt
+;;
 esac
