@@ -325,3 +325,70 @@ def test_init_scaling_matches_the_autograd_model(oracle, oracle_grid):
         assert abs(st["scale_fx"] - float(g("scale_fx0"))) / st["scale_fx"] < 1e-10, (st["scale_fx"], float(g("scale_fx0")))
         d = np.abs(st["scale_cx"].reshape(-1, 7) - g("scale_cx0")) / g("scale_cx0")
         assert d.max() < 1e-9, (nme, d.max(), np.unravel_index(d.argmax(), d.shape))
+
+
+def test_eigen_order_build_of_the_oracle_sums_like_eigens_vectorised_redux(tmp_path):
+    """oracle/eigen_redux.hpp (-DORACLE_EIGEN_REDUX=1): the L-BFGS dot products in the association of Eigen 3.3.7's redux for SSE2 -- four interleaved partial
+    sums, (s0 + s2 [+ last packet]) lanes, predux, scalar tail -- and the fixed-size block sums of calGradCTtoQT; the default build sums left to right.  Both
+    builds against a step-by-step numpy emulation of the respective order, bit for bit, for every length 1..40."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "liboracle_eig.so")
+    subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-DORACLE_EIGEN_REDUX=1", "-o", so, os.path.join(root, "oracle", "oracle_capi.cpp")])
+    E = C.CDLL(so)
+    D = C.CDLL(os.path.join(root, "oracle", "liboracle.so"))
+    for L in (E, D):
+        L.orc_dot.restype = C.c_double
+        L.orc_dot.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+        L.orc_block_sum.restype = C.c_double
+        L.orc_block_sum.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int]
+    assert E.orc_eigen_redux_enabled() == 1 and D.orc_eigen_redux_enabled() == 0
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def eigen_order(e):
+        n = len(e)
+        if n < 2:
+            return float(e[0])
+        a2, a1 = (n // 4) * 4, (n // 2) * 2
+        p0 = [e[0], e[1]]
+        if a1 > 2:
+            p1 = [e[2], e[3]]
+            for i in range(4, a2, 4):
+                p0 = [p0[0] + e[i], p0[1] + e[i + 1]]
+                p1 = [p1[0] + e[i + 2], p1[1] + e[i + 3]]
+            p0 = [p0[0] + p1[0], p0[1] + p1[1]]
+            if a1 > a2:
+                p0 = [p0[0] + e[a2], p0[1] + e[a2 + 1]]
+        r = p0[0] + p0[1]
+        for i in range(a1, n):
+            r = r + e[i]
+        return float(r)
+
+    rng = np.random.default_rng(3)
+    differ = 0
+    for n in range(1, 41):
+        a = rng.normal(size=n) * 10.0 ** rng.integers(-6, 6, n)
+        b = rng.normal(size=n)
+        e = a * b
+        seq = 0.0
+        for v in e:
+            seq = seq + v
+        assert D.orc_dot(dp(a), dp(b), n) == float(seq)
+        assert E.orc_dot(dp(a), dp(b), n) == eigen_order(e)
+        differ += int(eigen_order(e) != float(seq))
+    assert differ > 10                                          # the two orders really are different roundings
+    # block sums: 6 x 1 = p0 + (p1 + p2); 6 x 2 = one packet accumulator over the columns; 3 x 1 = packet + scalar; 3 x 2 = plain column-major
+    for rows, dim in ((6, 1), (6, 2), (3, 1), (3, 2)):
+        e = (rng.normal(size=(rows, dim)) * 10.0 ** rng.integers(-6, 6, (rows, dim))).copy()
+        if (rows, dim) == (6, 1):
+            want = (e[0, 0] + (e[2, 0] + e[4, 0])) + (e[1, 0] + (e[3, 0] + e[5, 0]))
+        elif (rows, dim) == (6, 2):
+            l0 = ((((e[0, 0] + e[2, 0]) + e[4, 0]) + e[0, 1]) + e[2, 1]) + e[4, 1]
+            l1 = ((((e[1, 0] + e[3, 0]) + e[5, 0]) + e[1, 1]) + e[3, 1]) + e[5, 1]
+            want = l0 + l1
+        elif (rows, dim) == (3, 1):
+            want = (e[0, 0] + e[1, 0]) + e[2, 0]
+        else:
+            want = ((((e[0, 0] + e[1, 0]) + e[2, 0]) + e[0, 1]) + e[1, 1]) + e[2, 1]
+        assert E.orc_block_sum(dp(np.ascontiguousarray(e)), rows, dim) == float(want), (rows, dim)
