@@ -677,15 +677,32 @@ static void kinoFreeWork(uph_kino* k) {
     k->d_nodes = k->d_heap = k->d_pos = k->d_key = k->d_table = nullptr;
     k->slots = 0;
 }
+static bool kinoTryAlloc(const uph_kino* k, int n, void* w[5]) {
+    for (int q = 0; q < 5; q++) w[q] = nullptr;
+    const bool ok = hipMalloc(&w[0], sizeof(KNode) * k->node_stride * n) == hipSuccess && hipMalloc(&w[1], sizeof(KHeap) * k->heap_stride * n) == hipSuccess &&
+                    hipMalloc(&w[2], sizeof(int) * k->node_stride * n) == hipSuccess && hipMalloc(&w[3], sizeof(int) * k->node_stride * n) == hipSuccess &&
+                    hipMalloc(&w[4], sizeof(int) * k->table_stride * n) == hipSuccess;
+    if (ok) return true;
+    (void)hipGetLastError();             // (out of memory is sticky until read)
+    for (int q = 0; q < 5; q++) { if (w[q]) hipFree(w[q]); w[q] = nullptr; }
+    return false;
+}
 static int kinoAllocWork(uph_kino* k, int want) {
+    void* w[5];
+    // a growing context first tries the new workspaces NEXT to the old ones: a failed growth then keeps the capacity it had (the searches of the call run
+    // in more rounds) instead of leaving the context without any
+    if (k->slots > 0 && want > k->slots) {
+        if (kinoTryAlloc(k, want, w)) {
+            kinoFreeWork(k);
+            k->d_nodes = w[0]; k->d_heap = w[1]; k->d_pos = w[2]; k->d_key = w[3]; k->d_table = w[4];
+            k->slots = want;
+            return UPH_OK;
+        }
+        // both sets do not fit together: release the old one and take what fits (below)
+    }
     kinoFreeWork(k);
     for (int n = std::max(1, want); n >= 1; n = n == 1 ? 0 : n / 2) {
-        const bool ok = hipMalloc(&k->d_nodes, sizeof(KNode) * k->node_stride * n) == hipSuccess && hipMalloc(&k->d_heap, sizeof(KHeap) * k->heap_stride * n) == hipSuccess &&
-                        hipMalloc(&k->d_pos, sizeof(int) * k->node_stride * n) == hipSuccess && hipMalloc(&k->d_key, sizeof(int) * k->node_stride * n) == hipSuccess &&
-                        hipMalloc(&k->d_table, sizeof(int) * k->table_stride * n) == hipSuccess;
-        if (ok) { k->slots = n; return UPH_OK; }
-        (void)hipGetLastError();             // (out of memory is sticky until read)
-        kinoFreeWork(k);
+        if (kinoTryAlloc(k, n, w)) { k->d_nodes = w[0]; k->d_heap = w[1]; k->d_pos = w[2]; k->d_key = w[3]; k->d_table = w[4]; k->slots = n; return UPH_OK; }
     }
     setError("uph_kino: hipMalloc of one search workspace (" + std::to_string(k->slot_bytes >> 20) + " MiB) failed");
     return UPH_ERR_HIP;
@@ -807,8 +824,9 @@ int uph_kino_plan_batch(uph_kino* k, int32_t B, const double* starts, const doub
     }
     KHIPCHK(hipSetDevice(k->device));
     if (k->auto_slots && k->slots < std::min((int)B, k->slots_cap)) {
-        // automatic workspaces follow the batch: first call, or a larger batch than any before (a few doublings at most over a context's life)
-        const int want = std::min(k->slots_cap, std::max((int)B, 16));
+        // automatic workspaces follow the batch, GEOMETRICALLY: first call, or a larger batch than any before -> at least twice the previous capacity, so a
+        // context fed slowly growing batches (17, 18, 19 ... queries) reallocates its ~4 MB-per-slot arrays a few times over its life, not at every call
+        const int want = std::min(k->slots_cap, std::max(std::max((int)B, 16), 2 * k->slots));
         const int r = kinoAllocWork(k, want);
         if (r != UPH_OK) return r;
         if (k->slots < want) k->slots_cap = k->slots;      // the device could not hold more: stop asking

@@ -734,6 +734,9 @@ struct uph_ctx {
     bool all_rejected = false;              // the last upload failed because EVERY problem was unsupported (not because of a misuse or a resource limit)
     std::vector<TrajFrame> frames;          // per-trajectory local frames of the uploaded batch (empty: the map's own frame, uph_common.hpp TrajFrame)
     std::vector<GridDev> grid_host_framed;  // ... and the per-trajectory grid descriptors made from them (source of the asynchronous copy)
+    GridDev frames_grid;                    // the map's descriptor the frames were formed from (geometry check at launch)
+    GridDev framed_from;                    // the map's descriptor the resident per-trajectory descriptors were made from
+    bool framed_valid = false;              // d_gridmem holds the framed descriptors of the current batch
     std::vector<int> origin;                // batch loaded by uph_optimize_batch_multi: the caller's index of each problem of this context's share (empty: identity)
     bool sample_f32 = false;                // fp32 sample arithmetic (uph_ctx_set_sample_precision)
     int xcd_group = 0;                      // experiment knob (uph_ctx_set_xcd_locality): > 0 = permute the launch order inside groups of that many workgroups for per-XCD L2 locality
@@ -821,15 +824,28 @@ static int launchSolver(uph_ctx* c, int mode, int repeat, bool async = false, hi
     GridDev grid = uphMapGrid(c->map);
     c->grid_host = grid;
     if (c->frames.empty()) {
+        c->framed_valid = false;
         if (c->d_gridmem.ensure(sizeof(GridDev))) return UPH_ERR_HIP;
         HIPCHK(hipMemcpyAsync(c->d_gridmem.p, &c->grid_host, sizeof(GridDev), hipMemcpyHostToDevice, c->stream));
     } else {
-        // local frames: one descriptor per trajectory = the map's with the frame's origin, bounds and cell-index offset (made from the map's CURRENT
-        // descriptor at every launch, like the shared one: a rebuilt map may have moved its cells)
-        if (c->d_gridmem.ensure(sizeof(GridDev) * c->frames.size())) return UPH_ERR_HIP;
-        c->grid_host_framed.assign(c->frames.size(), grid);
-        for (size_t b = 0; b < c->frames.size(); b++) applyFrame(c->grid_host_framed[b], c->frames[b]);
-        HIPCHK(hipMemcpyAsync(c->d_gridmem.p, c->grid_host_framed.data(), sizeof(GridDev) * c->frames.size(), hipMemcpyHostToDevice, c->stream));
+        // local frames: one descriptor per trajectory = the map's with the frame's origin, bounds and cell-index offset.  The frames were formed from the
+        // grid's geometry at upload: a map that has since been re-created with another origin / resolution / size would meet stale shifts -> refused.
+        // The descriptors (~250 B x B) are rebuilt and uploaded only when the map's descriptor changed since the last launch (a rebuilt map may have moved
+        // its cell array), not twice per solve.
+        const GridDev& fg = c->frames_grid;
+        if (grid.nx != fg.nx || grid.ny != fg.ny || grid.nyaw != fg.nyaw || grid.xy_res != fg.xy_res || grid.origin[0] != fg.origin[0] || grid.origin[1] != fg.origin[1] ||
+            grid.lo[0] != fg.lo[0] || grid.hi[0] != fg.hi[0] || grid.lo[1] != fg.lo[1] || grid.hi[1] != fg.hi[1]) {
+            setError("the map's geometry changed since this batch was uploaded (its per-trajectory local frames were formed from the old one): upload the batch again");
+            return UPH_ERR_INVALID;
+        }
+        if (!c->framed_valid || std::memcmp(&c->framed_from, &grid, sizeof(GridDev)) != 0) {
+            if (c->d_gridmem.ensure(sizeof(GridDev) * c->frames.size())) return UPH_ERR_HIP;
+            c->grid_host_framed.assign(c->frames.size(), grid);
+            for (size_t b = 0; b < c->frames.size(); b++) applyFrame(c->grid_host_framed[b], c->frames[b]);
+            HIPCHK(hipMemcpyAsync(c->d_gridmem.p, c->grid_host_framed.data(), sizeof(GridDev) * c->frames.size(), hipMemcpyHostToDevice, c->stream));
+            c->framed_from = grid;
+            c->framed_valid = true;
+        }
     }
     if (c->d_parammem.ensure(sizeof(OptParams))) return UPH_ERR_HIP;
     HIPCHK(hipMemcpyAsync(c->d_parammem.p, &c->P, sizeof(OptParams), hipMemcpyHostToDevice, c->stream));
@@ -1096,6 +1112,8 @@ int uph_batch_upload(uph_ctx* c, int32_t B, const uph_problem* probs) {
     // grid's origin, so the translation of the inputs is exact and the lookups see the same cells.  The reference's maps (10 m x 10 m) stay
     // in the map's frame: frames empty, the plain lookup code path.
     c->frames.clear();
+    c->framed_valid = false;
+    c->frames_grid = tg;
     if (std::max(std::max(std::fabs(tg.minb[0]), std::fabs(tg.maxb[0])), std::max(std::fabs(tg.minb[1]), std::fabs(tg.maxb[1]))) > FRAME_EXTENT) {
         c->frames.resize(B);
         for (int b = 0; b < B; b++) {
