@@ -72,4 +72,66 @@ for v in default flip1 flip9 flip10 flip16 sc3 default flip16; do
   timeout 400 python tools/ab_eval.py 16384 0 2>&1 | tail -1
 done 2>&1 | tee $OUT/ab.txt
 ;;
+5)
+# initScaling regrouped (3 + 2 + 2 constraints, operator rows in batches of 4 columns): scaling-kernel ms and bit-identity of the results; then the whole GPU tier
+OUT=gpurun_out/r06e; mkdir -p $OUT
+for v in default sc3w4 sc2w4 sc3 default sc3w4; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  [ -z "${UNEVENHIP_LIB:-}" ] || [ -f "$UNEVENHIP_LIB" ] || continue
+  echo "== $v"
+  timeout 400 python tools/ab_eval.py 16384 0 2>&1 | tail -1
+done 2>&1 | tee $OUT/ab.txt
+unset UNEVENHIP_LIB
+timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -6 $OUT/gpu_tests.txt | cut -c1-400
+;;
+7)
+# blocked two-loop: the state-machine tests first (teacher-forced late states: ring wrap, cautious skip ...), per-evaluation parity, then the A/B against the plain recursion
+OUT=gpurun_out/r06f; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_forced.py tests/test_gpu_parity.py tests/test_gpu_lanes.py tests/test_gpu_edge.py -m gpu -q -x 2>&1 | tail -12 | cut -c1-300 | tee $OUT/tests.txt
+for v in default seq default seq; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  echo "== $v"
+  timeout 400 python tools/ab_eval.py 16384 5.5 2>&1 | tail -2
+done 2>&1 | tee $OUT/ab.txt
+unset UNEVENHIP_LIB
+timeout 300 python - <<'PY' 2>&1 | tail -4 | tee $OUT/single.txt
+import os, sys
+sys.path.insert(0, os.getcwd())
+import uneven_planner_amd as U
+from uneven_planner_amd import scenes
+m = U.UnevenMap(); m.build(scenes.make_hill_cloud())
+nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
+probs = scenes.random_problems(256, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
+for tag, pp in (("single hill", [scenes.hill_problem()]), ("B256", probs)):
+    o = U.ALMTrajOpt(m); o.upload(pp)
+    for _ in range(3):
+        o.set_rho(1.0); o.solve(); st = o.stats()
+    print("%s: kernel %.3f ms + scaling %.3f ms, iters %d, %.0f traj/s" % (tag, st["kernel_ms"], st["prepare_ms"], st["lbfgs_iters"], len(pp) / (st["kernel_ms"] + st["prepare_ms"]) * 1e3))
+PY
+;;
+8)
+# blocked two-loop, second pass: unconditional prefetch; phase cycles per evaluation (in-kernel counters) blocked vs plain recursion; A/B
+OUT=gpurun_out/r06g; mkdir -p $OUT
+for v in cyc cycseq; do
+  export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so
+  echo "== $v (B = 16384, 128 lanes)"; timeout 300 python tools/phase_breakdown.py 16384 2>&1 | grep -E "cycles/eval|kernel_ms|residency"
+  echo "== $v (single trajectory class: B = 64, 512 lanes)"; timeout 300 python tools/phase_breakdown.py 64 2>&1 | grep -E "cycles/eval|kernel_ms"
+done 2>&1 | tee $OUT/phases.txt
+for v in default seq default seq; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  echo "== $v"
+  timeout 400 python tools/ab_eval.py 16384 5.5 2>&1 | tail -2
+done 2>&1 | tee $OUT/ab.txt
+;;
+6)
+# end-of-round record on the final sources: smoke, the whole GPU tier, profile.sh (bench line, kernel trace, counter passes, calibration) for the headline and for --workload astar
+OUT=gpurun_out/r06z; mkdir -p $OUT
+timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 | tee $OUT/smoke.txt
+timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -4 $OUT/gpu_tests.txt | cut -c1-400
+mkdir -p build/micro; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/micro/fetch_calib.hip -o build/micro/fetch_calib 2>/dev/null
+bash tools/profile.sh r06z 2>&1 | tail -40
+WL=astar bash tools/profile.sh r06z_astar 2>&1 | tail -15
+;;
 esac
