@@ -46,6 +46,8 @@ PMC_FILE = "pmc_traffic.json"      # (--workload astar: pmc_traffic_astar.json -
 
 def pmc_counters(batch):
     """the committed counter pass (profiles/pmc_traffic*.json, written by tools/profile.sh) if it describes THIS kernel, workload and batch size, else (None, why)"""
+    if LIVE_PMC is not None and int(LIVE_PMC.get("batch", -1)) == int(batch):
+        return LIVE_PMC, None
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             t = json.load(f)
@@ -57,6 +59,61 @@ def pmc_counters(batch):
         return None, "STALE: the committed counter pass (%s, kernel sources %s) is not of this build's kernel sources (%s) -- re-run tools/profile.sh" % (
             t.get("tag"), t.get("kernel_src_sha"), kernel_sources_sha())
     return t, None
+
+
+LIVE_PMC = None      # filled by live_counter_passes(): the same dict shape as profiles/pmc_traffic*.json, measured by THIS invocation
+
+
+def live_counter_passes(args, workload_flag):
+    """rocprofv3 --pmc passes of this very command, run as children of this bench.py invocation (N = 1, default run): one pass per counter group, each a
+    `bench.py --steps 1 --warmup 0 --no-cpu --no-extras --no-configs --no-live-counters` under `rocprofv3 --pmc ... ` (counters only: no tracing domains beside them),
+    the solve kernel's rows (MODE 2) summed.  Returns a dict like profiles/pmc_traffic.json or None (no rocprofv3, a pass failed or timed out: the line then falls back to
+    the committed pass).  ~20 s per pass."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "no rocprofv3 on this box"
+    groups = [("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"),
+              ("SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES")]
+    vals, launch_ms, t_all = {}, None, time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="uph_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for g in groups:
+            out = os.path.join(tmp, g[0])
+            cmd = [exe, "--pmc"] + list(g) + ["--output-format", "csv", "-d", out, "-o", "c", "--", sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0",
+                                               "--no-cpu", "--no-extras", "--no-configs", "--no-live-counters", "--batch", str(args.batch)] + workload_flag + (["--lanes", str(args.lanes)] if args.lanes else [])
+            try:
+                r = subprocess.run(cmd, cwd=os.environ.get("TMPDIR", "/tmp"), capture_output=True, text=True, timeout=float(os.environ.get("UPH_BENCH_PMC_LIMIT", "150")))
+            except subprocess.TimeoutExpired:
+                return None, "the %s counter pass exceeded its limit" % g[0]
+            if r.returncode != 0:
+                return None, "the %s counter pass failed (rc %d): %s" % (g[0], r.returncode, (r.stderr or "")[-300:])
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if line and launch_ms is None:
+                launch_ms = json.loads(line[-1])["roofline"]["avg_launch_ms"]      # (under the profiler: the counters' own launch)
+            got = False
+            for root_, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        with open(os.path.join(root_, f)) as fh:
+                            for row in csv.DictReader(fh):
+                                k = row["Kernel_Name"].replace(" ", "")
+                                if re.search(r"uph_solver_kernel<\d+,\d+,2(,(false|true))?>", k) or re.search(r"uph_solver_kernelILi\d+ELi\d+ELi2E", k):
+                                    vals[row["Counter_Name"]] = vals.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                                    got = True
+            if not got:
+                return None, "the %s counter pass produced no rows of the solve kernel" % g[0]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"batch": args.batch, "tag": "rocprofv3 --pmc passes run by this bench.py invocation (%d passes, %.0f s)" % (len(groups), time.perf_counter() - t_all),
+            "fetch_kib": vals.get("FETCH_SIZE", 0.0), "write_kib": vals.get("WRITE_SIZE", 0.0), "launches": 1, "sq_active_inst_valu": vals.get("SQ_ACTIVE_INST_VALU", 0.0),
+            "sq_wave_cycles": vals.get("SQ_WAVE_CYCLES", 0.0), "sq_wait_any": vals.get("SQ_WAIT_ANY", 0.0), "sq_insts_valu": vals.get("SQ_INSTS_VALU", 0.0),
+            "sq_insts_valu_mfma_f64": vals.get("SQ_INSTS_VALU_MFMA_F64", 0.0), "sq_insts_valu_mfma_mops_f64": vals.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0),
+            "sq_valu_mfma_busy_cycles": vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), "launch_ms": launch_ms, "kernel_src_sha": kernel_sources_sha(), "git_head": "this run", "live": True}, None
 
 
 def pmc_traffic(batch, stream_bytes):
@@ -507,6 +564,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the penalty-kernel and small-batch measurements (profiling runs)")
     ap.add_argument("--extras-multi", action="store_true", help="run rank 0's single-GPU extras (penalty kernel, small batches, front end ...) even when N > 1 (default: N = 1 only)")
+    ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc passes of this command as children (N = 1 default run); roofline.traffic / valu_busy / mfma then "
+                                                                     "come from the committed counter pass under profiles/, if it matches this build")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config block (BASELINE.json configs[0..4]: desert B = 256, volcano map build, km^2 B = 4096 fp64 / fp32 ...)")
     ap.add_argument("--workload", choices=("hill", "astar", "km2"), default="hill",
                     help="hill: the BASELINE metric's scene, Hermite stand-in initial paths (default).  astar: the same scene and goal protocol with the initial paths the "
@@ -893,9 +952,20 @@ def main():
         per_launch_bytes = (sample_evals * bytes_per_sample + hist_bytes + iters * 2 * 8 * (n_sum / max(1, args.batch))) / K
         avg_ms = float(np.mean(kernel_ms))
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        live_why = None
+        if world == 1 and not km2 and not args.no_live_counters and not args.no_extras and not args.no_cpu:
+            # driver-observed counters: the --pmc passes of this command run here, now; a failure falls back to the committed pass
+            global LIVE_PMC
+            try:
+                LIVE_PMC, live_why = live_counter_passes(args, ["--workload", "astar"] if astar_wl else [])
+            except Exception as e:
+                LIVE_PMC, live_why = None, repr(e)
         tr = None if km2 else pmc_traffic(args.batch, hist_bytes / K + sample_evals * 14 * 8 / K)
         pc, pc_why = (None, "km2 workload: no committed counter pass") if km2 else pmc_counters(args.batch)
-        traffic, traffic_src = (tr[0], "committed rocprofv3 --pmc passes of this command (%s), not measured in this run" % tr[1]) if tr else (None, pc_why)
+        if tr and LIVE_PMC is not None:
+            traffic, traffic_src = tr[0], "%s; FETCH_SIZE calibrated as profiles/*_fetch_calibration.txt prescribes (contiguous reads counted at 1/2)" % tr[1]
+        else:
+            traffic, traffic_src = (tr[0], "committed rocprofv3 --pmc passes of this command (%s), not measured in this run%s" % (tr[1], ("; live passes: " + live_why) if live_why else "")) if tr else (None, (pc_why or "") + (("; live passes: " + live_why) if live_why else ""))
         # the bound that actually binds: VALU issue.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over all waves; per SIMD
         # (4 per CU, 256 CUs) and per launch of the committed pass, against that pass's own launch duration at the 2.4 GHz shader clock
         valu_busy = wait_frac = None
@@ -945,7 +1015,10 @@ def main():
                          "algorithmic_bytes_per_launch": per_launch_bytes, "frac_without_unwritten_residuals": moved_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "sample_bytes_per_launch": sample_evals * bytes_per_sample / K, "history_bytes_per_launch": hist_bytes / K,
                          "valu_busy": valu_busy, "wave_wait_frac": wait_frac, "mfma": mfma,
-                         "valu_busy_source": ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch x 2.4 GHz) of the committed counter pass %s (git %s, kernel sources %s, launch %.1f ms)" % (
+                         # an fp64 vector instruction is priced at 4 cycles above; this part sustains 58.7 of the 78.6 TFLOP/s that would mean (tools/micro/fma_rate.hip: 5.4 cycles per
+                         # fp64 FMA) and the quarter-rate instructions of the sample code take 16: by the measured FMA rate alone the pipes are this busy
+                         "valu_busy_at_measured_fp64_issue_rate": (valu_busy * 78.6432 / 58.7) if valu_busy is not None else None,
+                         "valu_busy_source": ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch x 2.4 GHz) of the counter pass: %s (git %s, kernel sources %s, launch %.1f ms)" % (
                              pc.get("tag"), pc.get("git_head"), pc.get("kernel_src_sha"), pc.get("launch_ms", float("nan")))) if pc is not None else pc_why,
                          "kernel_src_sha": kernel_sources_sha()},
         }

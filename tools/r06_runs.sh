@@ -124,6 +124,20 @@ for v in default seq default seq; do
   timeout 400 python tools/ab_eval.py 16384 5.5 2>&1 | tail -2
 done 2>&1 | tee $OUT/ab.txt
 ;;
+9)
+# the default bench line with its own live counter passes (rocprofv3 --pmc children of bench.py)
+OUT=gpurun_out/r06h; mkdir -p $OUT; export TMPDIR=/tmp
+( time timeout 1200 python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real; echo "bench rc $?"; tail -3 $OUT/bench.err
+python - $OUT/bench.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+rf = r["roofline"]
+print("value %.0f  launch %.1f ms  frac %.3f" % (r["value"], rf["avg_launch_ms"], rf["frac"]))
+print("traffic", rf["traffic"], "|", rf["traffic_source"])
+print("valu_busy", rf["valu_busy"], rf["valu_busy_at_measured_fp64_issue_rate"], "wait", rf["wave_wait_frac"], "|", rf["valu_busy_source"])
+print("mfma", json.dumps(rf["mfma"])[:300])
+PY
+;;
 6)
 # end-of-round record on the final sources: smoke, the whole GPU tier, profile.sh (bench line, kernel trace, counter passes, calibration) for the headline and for --workload astar
 OUT=gpurun_out/r06z; mkdir -p $OUT
