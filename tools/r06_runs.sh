@@ -144,6 +144,13 @@ OUT=gpurun_out/r06z; mkdir -p $OUT
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 | tee $OUT/smoke.txt
 timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
 tail -4 $OUT/gpu_tests.txt | cut -c1-400
+# the kernel arithmetic of this round's library against round 5's final library (built from commit 0fb623f): same bits -> round 5's N = 4096 / 16384 drift tables stand
+for v in default r05; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  [ -z "${UNEVENHIP_LIB:-}" ] || [ -f "$UNEVENHIP_LIB" ] || continue
+  echo "== $v"; timeout 400 python tools/ab_eval.py 16384 0 2>&1 | tail -1
+done 2>&1 | tee $OUT/bit_identity_vs_r05.txt
+unset UNEVENHIP_LIB
 mkdir -p build/micro; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/micro/fetch_calib.hip -o build/micro/fetch_calib 2>/dev/null
 bash tools/profile.sh r06z 2>&1 | tail -40
 WL=astar bash tools/profile.sh r06z_astar 2>&1 | tail -15
