@@ -138,6 +138,25 @@ print("valu_busy", rf["valu_busy"], rf["valu_busy_at_measured_fp64_issue_rate"],
 print("mfma", json.dumps(rf["mfma"])[:300])
 PY
 ;;
+10)
+# after the disc-walk refactor of the map build (one predicate for the sizing and the staging kernel): the whole GPU tier + the map-build timing
+OUT=gpurun_out/r06i; mkdir -p $OUT
+timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -4 $OUT/gpu_tests.txt | cut -c1-300
+timeout 200 python - <<'PY' 2>&1 | tail -3 | tee $OUT/map_ms.txt
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import uneven_planner_amd as U
+from uneven_planner_amd import scenes
+for tag, xyz, prm in (("hill", scenes.make_hill_cloud(), None), ("vocano", np.load("tests/golden/vocano_xyz.npz")["xyz"], dict(max_rho=0.08)), ("forest", np.load("tests/golden/forest_xyz.npz")["xyz"], None)):
+    m = U.UnevenMap(prm); m.build(xyz, download=False)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); m.build(xyz, download=False); ts.append(time.perf_counter() - t0)
+    print(tag, "uph_map_build %.2f ms, stages" % (min(ts) * 1e3), {k: round(v, 3) for k, v in m.build_stats()["stages_ms"].items()})
+PY
+;;
 6)
 # end-of-round record on the final sources: smoke, the whole GPU tier, profile.sh (bench line, kernel trace, counter passes, calibration) for the headline and for --workload astar
 OUT=gpurun_out/r06z; mkdir -p $OUT

@@ -152,6 +152,44 @@ __device__ int nearest2DGlobal(const CloudDev& cd, float qx, float qy, float* zo
     return best;
 }
 
+// The disc of points a column stages: every point of the xy-bucketed cloud within Rst = 0.12 + max(ellipsoid) + 1 mm of the cell centre, visited bucket row by
+// bucket row in cloud order.  ONE definition for the two kernels that must agree on it -- uph_map_build_kernel (stages the disc into LDS) and uph_disc_cap_kernel
+// (counts the largest disc so that the host can size that LDS window): sink(keep, p, ballot) is called once per 64-point batch by the whole wave, with this lane's
+// verdict and point and the wave's ballot of verdicts.
+struct DiscWalk {
+    float Rst, fcx, fcy;
+    int bxa, bxb, bya, byb;
+};
+__device__ __forceinline__ DiscWalk discOf(const GridDev& g, const CloudDev& cd, int x, int y, double ell_x, double ell_y, double ell_z) {
+    DiscWalk w;
+    const double ccx = (x + 0.5) * g.xy_res + g.origin[0];           // indexToPos, uneven_map.h:419-425
+    const double ccy = (y + 0.5) * g.xy_res + g.origin[1];
+    const double box_r = fmax(fmax(ell_x, ell_y), ell_z);            // uneven_map.cpp:319
+    w.Rst = (float)(0.12 + box_r) + 1.0e-3f;                         // staging radius around the cell centre
+    w.fcx = (float)ccx; w.fcy = (float)ccy;
+    w.bxa = max(0, (int)floorf((w.fcx - w.Rst - cd.bx0) / cd.bsize)); w.bxb = min(cd.bnx - 1, (int)floorf((w.fcx + w.Rst - cd.bx0) / cd.bsize));
+    w.bya = max(0, (int)floorf((w.fcy - w.Rst - cd.by0) / cd.bsize)); w.byb = min(cd.bny - 1, (int)floorf((w.fcy + w.Rst - cd.by0) / cd.bsize));
+    return w;
+}
+template <class SINK>
+__device__ __forceinline__ void walkDisc(const DiscWalk& w, const CloudDev& cd, int lane, SINK sink) {
+    for (int bx = w.bxa; bx <= w.bxb; bx++) {
+        if (w.bya > w.byb) break;
+        const int t0 = cd.bstart[bx * cd.bny + w.bya], t1 = cd.bstart[bx * cd.bny + w.byb + 1];
+        for (int base = t0; base < t1; base += 64) {
+            const int t = base + lane;
+            bool keep = false;
+            float4 p = make_float4(0, 0, 0, 0);
+            if (t < t1) {
+                p = cd.pts[t];
+                const float dx = p.x - w.fcx, dy = p.y - w.fcy;
+                keep = (dx * dx + dy * dy) <= w.Rst * w.Rst;
+            }
+            sink(keep, p, __ballot(keep));
+        }
+    }
+}
+
 // one wave64 per (x,y) column of the slab [x0, x1)
 __global__ __launch_bounds__(64) void uph_map_build_kernel(GridDev g, CloudDev cd, double* __restrict__ cells, int x0, int x1, int iter_num,
                                                            double ell_x, double ell_y, double ell_z, int lds_cap, int* __restrict__ overflow) {
@@ -163,30 +201,15 @@ __global__ __launch_bounds__(64) void uph_map_build_kernel(GridDev g, CloudDev c
     const double ccx = (x + 0.5) * g.xy_res + g.origin[0];           // indexToPos, uneven_map.h:419-425
     const double ccy = (y + 0.5) * g.xy_res + g.origin[1];
     const double box_r = fmax(fmax(ell_x, ell_y), ell_z);            // uneven_map.cpp:319
-    const float Rst = (float)(0.12 + box_r) + 1.0e-3f;               // staging radius around the cell centre
-    // ---- stage the neighbourhood into LDS (order preserving)
-    const float fcx = (float)ccx, fcy = (float)ccy;
-    const int bxa = max(0, (int)floorf((fcx - Rst - cd.bx0) / cd.bsize)), bxb = min(cd.bnx - 1, (int)floorf((fcx + Rst - cd.bx0) / cd.bsize));
-    const int bya = max(0, (int)floorf((fcy - Rst - cd.by0) / cd.bsize)), byb = min(cd.bny - 1, (int)floorf((fcy + Rst - cd.by0) / cd.bsize));
+    // ---- stage the neighbourhood into LDS (order preserving): the disc of discOf / walkDisc, the definition uph_disc_cap_kernel sized the window with
+    const DiscWalk dw = discOf(g, cd, x, y, ell_x, ell_y, ell_z);
+    const float Rst = dw.Rst, fcx = dw.fcx, fcy = dw.fcy;
     int count = 0;
-    for (int bx = bxa; bx <= bxb; bx++) {
-        if (bya > byb) break;
-        const int t0 = cd.bstart[bx * cd.bny + bya], t1 = cd.bstart[bx * cd.bny + byb + 1];
-        for (int base = t0; base < t1; base += 64) {
-            const int t = base + lane;
-            bool keep = false;
-            float4 p = make_float4(0, 0, 0, 0);
-            if (t < t1) {
-                p = cd.pts[t];
-                const float dx = p.x - fcx, dy = p.y - fcy;
-                keep = (dx * dx + dy * dy) <= Rst * Rst;
-            }
-            const unsigned long long mask = __ballot(keep);
-            const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-            if (keep && pos < lds_cap) spts[pos] = p;
-            count += __popcll(mask);
-        }
-    }
+    walkDisc(dw, cd, lane, [&](bool keep, const float4& p, unsigned long long mask) {
+        const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep && pos < lds_cap) spts[pos] = p;
+        count += __popcll(mask);
+    });
     if (count > lds_cap) {                     // the host sized the staging area for the largest window: report, never fit silently on a truncated disc
         if (lane == 0) atomicExch(overflow, 1);
         count = lds_cap;
@@ -500,7 +523,7 @@ __global__ void uph_bstart_kernel(const int* __restrict__ skey, int n, int nb, i
     bstart[b] = lo;
 }
 // LDS capacity of the plane-fit kernel's staging area = the largest point count of any disc it stages: one wave per (x, y) column of the slab counts the
-// points within the staging radius of its cell centre with the kernel's own predicate (same buckets, same float expression).  (Until round 5 the bound
+// points within the staging radius of its cell centre with the kernel's own predicate (discOf / walkDisc above: one definition for both kernels).  (Until round 5 the bound
 // was the largest count of a 9 x 9 window of 0.16 m buckets -- several times the disc of 0.32 m radius: on the reference's forest cloud, where trunks and
 // canopy stack thousands of points over one column, that bound passed the LDS limit although the largest disc holds 4 500 points = 72 KB.)
 __global__ __launch_bounds__(64) void uph_disc_cap_kernel(GridDev g, CloudDev cd, int x0, int x1, double ell_x, double ell_y, double ell_z, int* __restrict__ cap) {
@@ -508,28 +531,8 @@ __global__ __launch_bounds__(64) void uph_disc_cap_kernel(GridDev g, CloudDev cd
     const int x = x0 + col / g.ny, y = col % g.ny;
     if (x >= x1) return;
     const int lane = threadIdx.x;
-    const double ccx = (x + 0.5) * g.xy_res + g.origin[0];
-    const double ccy = (y + 0.5) * g.xy_res + g.origin[1];
-    const double box_r = fmax(fmax(ell_x, ell_y), ell_z);
-    const float Rst = (float)(0.12 + box_r) + 1.0e-3f;               // (the expressions of uph_map_build_kernel, literally)
-    const float fcx = (float)ccx, fcy = (float)ccy;
-    const int bxa = max(0, (int)floorf((fcx - Rst - cd.bx0) / cd.bsize)), bxb = min(cd.bnx - 1, (int)floorf((fcx + Rst - cd.bx0) / cd.bsize));
-    const int bya = max(0, (int)floorf((fcy - Rst - cd.by0) / cd.bsize)), byb = min(cd.bny - 1, (int)floorf((fcy + Rst - cd.by0) / cd.bsize));
     int count = 0;
-    for (int bx = bxa; bx <= bxb; bx++) {
-        if (bya > byb) break;
-        const int t0 = cd.bstart[bx * cd.bny + bya], t1 = cd.bstart[bx * cd.bny + byb + 1];
-        for (int base = t0; base < t1; base += 64) {
-            const int t = base + lane;
-            bool keep = false;
-            if (t < t1) {
-                const float4 p = cd.pts[t];
-                const float dx = p.x - fcx, dy = p.y - fcy;
-                keep = (dx * dx + dy * dy) <= Rst * Rst;
-            }
-            count += __popcll(__ballot(keep));
-        }
-    }
+    walkDisc(discOf(g, cd, x, y, ell_x, ell_y, ell_z), cd, lane, [&](bool, const float4&, unsigned long long mask) { count += __popcll(mask); });
     if (lane == 0) atomicMax(cap, count);
 }
 
