@@ -157,6 +157,35 @@ for tag, xyz, prm in (("hill", scenes.make_hill_cloud(), None), ("vocano", np.lo
     print(tag, "uph_map_build %.2f ms, stages" % (min(ts) * 1e3), {k: round(v, 3) for k, v in m.build_stats()["stages_ms"].items()})
 PY
 ;;
+11)
+# latency class: dense knot solve (difference-form operator) at 512 lanes -- the lane-variant tests (1e-9 against the oracle), then single trajectory / B = 256 / desert B = 256 against the Thomas build
+OUT=gpurun_out/r06j; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_lanes.py tests/test_gpu_parity.py tests/test_gpu_edge.py tests/test_gpu_buckets.py -m gpu -q -x 2>&1 | tail -8 | cut -c1-300 | tee $OUT/tests.txt
+for v in default thomas512 default thomas512; do
+  if [ "$v" = default ]; then unset UNEVENHIP_LIB; else export UNEVENHIP_LIB=$GRAFT_REPO_ROOT/build/variants/libunevenhip_$v.so; fi
+  echo "== $v"
+  timeout 300 python - <<'PY' 2>&1 | tail -4
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import uneven_planner_amd as U
+from uneven_planner_amd import scenes
+m = U.UnevenMap(); m.build(scenes.make_hill_cloud())
+nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
+probs = scenes.random_problems(256, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
+for tag, pp in (("single hill", [scenes.hill_problem()]), ("B64", probs[:64]), ("B256", probs)):
+    o = U.ALMTrajOpt(m); o.upload(pp)
+    ks = []
+    for _ in range(3):
+        o.set_rho(1.0); o.solve(); st = o.stats(); ks.append(st["kernel_ms"] + st["prepare_ms"])
+    out = o.download(full=False)
+    print("%s: %.3f ms (kernel + scaling), iters %d, evals %d, %.4f ms / iteration, %.0f traj/s, converged %.2f" % (tag, min(ks), st["lbfgs_iters"], st["evals"], st["kernel_ms"] / st["lbfgs_iters"] * (len(pp) if len(pp) == 1 else 1), len(pp) / min(ks) * 1e3, np.mean([q["ret"] == 0 for q in out])))
+o = U.ALMTrajOpt(m); o.upload([scenes.hill_problem()] * 256); o.init_scaling_batch()
+o.eval_batch(None, repeat=20); o.eval_batch(None, repeat=20)
+print("hill x 256 evaluation: %.2f us" % (o.stats()["kernel_ms"] * 1e3 / 20))
+PY
+done 2>&1 | tee $OUT/ab.txt
+;;
 6)
 # end-of-round record on the final sources: smoke, the whole GPU tier, profile.sh (bench line, kernel trace, counter passes, calibration) for the headline and for --workload astar
 OUT=gpurun_out/r06z; mkdir -p $OUT
