@@ -774,6 +774,19 @@ def main():
             torch.cuda.synchronize()
             extras["traj_opts_per_s_B%d" % Bx] = Bx * 3 / (time.perf_counter() - t1)
             del o2
+        # twice the headline's batch (same protocol, seeds continued): what the launch tail -- workgroups finishing below full residency, 7 % of a launch at 16384 -- is worth
+        if args.batch == 16384:
+            pb2 = probs + scenes.random_problems(args.batch, seed0=1000 + 8 * args.batch, occ_r2=m.occ_r2_buffer, grid=gridinfo)
+            o4 = U.ALMTrajOpt(m)
+            o4.upload(pb2)
+            o4.set_rho(1.0); o4.solve()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                o4.set_rho(1.0); o4.solve()
+            torch.cuda.synchronize()
+            extras["traj_opts_per_s_B%d" % len(pb2)] = len(pb2) * 2 / (time.perf_counter() - t1)
+            del o4, pb2
         # configs[4] "fp32" on the same scene: fp32 arithmetic in the sample phase (uph_ctx_set_sample_precision), B = 8192, three solves
         if args.batch >= 8192 and not args.fp32:
             o3 = U.ALMTrajOpt(m)

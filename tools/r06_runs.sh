@@ -186,6 +186,17 @@ print("hill x 256 evaluation: %.2f us" % (o.stats()["kernel_ms"] * 1e3 / 20))
 PY
 done 2>&1 | tee $OUT/ab.txt
 ;;
+12)
+# soak of the final build (mixed batch sizes through every kernel-selection regime + front-end queries: return codes, device-memory growth) and the default bench line
+OUT=gpurun_out/r06k; mkdir -p $OUT; export TMPDIR=/tmp
+UPH_SOAK_ITERS=600 timeout 900 python tools/soak.py 2>&1 | tail -6 | tee $OUT/soak.txt
+( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real | tee $OUT/bench_wall.txt; tail -2 $OUT/bench.err
+python - $OUT/bench.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+print("value %.0f  ms/step %.2f  launch %.1f ms  frac %.3f  B32768 %.0f  B8192 %.0f B256 %.0f  traffic %.4g (%s)" % (r["value"], r["ms_per_step"], r["roofline"]["avg_launch_ms"], r["roofline"]["frac"], r.get("traj_opts_per_s_B32768", 0), r.get("traj_opts_per_s_B8192", 0), r.get("traj_opts_per_s_B256", 0), r["roofline"]["traffic"] or 0, r["roofline"]["traffic_source"][:60]))
+PY
+;;
 6)
 # end-of-round record on the final sources: smoke, the whole GPU tier, profile.sh (bench line, kernel trace, counter passes, calibration) for the headline and for --workload astar
 OUT=gpurun_out/r06z; mkdir -p $OUT
