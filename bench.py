@@ -85,7 +85,7 @@ def live_counter_passes(args, workload_flag):
         for g in groups:
             out = os.path.join(tmp, g[0])
             cmd = [exe, "--pmc"] + list(g) + ["--output-format", "csv", "-d", out, "-o", "c", "--", sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0",
-                                               "--no-cpu", "--no-extras", "--no-configs", "--no-live-counters", "--batch", str(args.batch)] + workload_flag + (["--lanes", str(args.lanes)] if args.lanes else [])
+                                               "--no-cpu", "--no-extras", "--no-configs", "--no-live-counters", "--batch", str(args.batch)] + workload_flag + (["--lanes", str(args.lanes)] if args.lanes else []) + (["--fp32"] if args.fp32 else [])
             try:
                 r = subprocess.run(cmd, cwd=os.environ.get("TMPDIR", "/tmp"), capture_output=True, text=True, timeout=float(os.environ.get("UPH_BENCH_PMC_LIMIT", "150")))
             except subprocess.TimeoutExpired:
@@ -973,8 +973,9 @@ def main():
                 LIVE_PMC, live_why = live_counter_passes(args, ["--workload", "astar"] if astar_wl else [])
             except Exception as e:
                 LIVE_PMC, live_why = None, repr(e)
-        tr = None if km2 else pmc_traffic(args.batch, hist_bytes / K + sample_evals * 14 * 8 / K)
-        pc, pc_why = (None, "km2 workload: no committed counter pass") if km2 else pmc_counters(args.batch)
+        no_pass = "km2 workload: no committed counter pass" if km2 else ("fp32 sample arithmetic: the committed counter pass is of the fp64 kernels" if (args.fp32 and LIVE_PMC is None) else None)
+        tr = None if no_pass else pmc_traffic(args.batch, hist_bytes / K + sample_evals * 14 * 8 / K)
+        pc, pc_why = (None, no_pass) if no_pass else pmc_counters(args.batch)
         if tr and LIVE_PMC is not None:
             traffic, traffic_src = tr[0], "%s; FETCH_SIZE calibrated as profiles/*_fetch_calibration.txt prescribes (contiguous reads counted at 1/2)" % tr[1]
         else:

@@ -197,6 +197,22 @@ r = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
 print("value %.0f  ms/step %.2f  launch %.1f ms  frac %.3f  B32768 %.0f  B8192 %.0f B256 %.0f  traffic %.4g (%s)" % (r["value"], r["ms_per_step"], r["roofline"]["avg_launch_ms"], r["roofline"]["frac"], r.get("traj_opts_per_s_B32768", 0), r.get("traj_opts_per_s_B8192", 0), r.get("traj_opts_per_s_B256", 0), r["roofline"]["traffic"] or 0, r["roofline"]["traffic_source"][:60]))
 PY
 ;;
+13)
+# the other forms of the bench call after this round's surgery: km2 (with its parity floor), fp32 samples + pipelined, the tiled km2 form refuses N = 1 gracefully
+OUT=gpurun_out/r06l; mkdir -p $OUT
+timeout 900 python bench.py --workload km2 --steps 3 --warmup 1 > $OUT/bench_km2.json 2> $OUT/bench_km2.err; echo "km2 rc $?"; tail -2 $OUT/bench_km2.err
+python - $OUT/bench_km2.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+print("km2 value %.0f frac %.3f converged %.3f" % (r["value"], r["roofline"]["frac"], r["converged_frac"]), json.dumps(r.get("parity_floor"))[:400])
+PY
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu --no-extras --pipelined --fp32 > $OUT/bench_fp32_pipelined.json 2> $OUT/bench_fp32.err; echo "fp32 rc $?"; tail -2 $OUT/bench_fp32.err
+python - $OUT/bench_fp32_pipelined.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+print("fp32 samples value %.0f dtype %s pipelined %s traffic_source %s" % (r["value"], r["dtype"], r.get("pipelined"), r["roofline"]["traffic_source"][:90]))
+PY
+;;
 6)
 # end-of-round record on the final sources: smoke, the whole GPU tier, profile.sh (bench line, kernel trace, counter passes, calibration) for the headline and for --workload astar
 OUT=gpurun_out/r06z; mkdir -p $OUT
