@@ -554,6 +554,74 @@ def measure_configs(args, torch, U, scenes, m_hill, single_line, pk):
     return {"seconds": time.perf_counter() - t_all, "entries": cfg}
 
 
+def dist_selftest(torch, dist, rank, world, tdev):
+    """collective self-test on the run's own communicator, before anything is measured: an all-gather of the rank ids and a sum with known answers"""
+    with Stage("collective self-test", 120, rank) as stg:
+        mine = torch.full((1024,), float(rank), dtype=torch.float64, device=tdev)
+        allr = torch.empty(1024 * world, dtype=torch.float64, device=tdev)
+        dist.all_gather_into_tensor(allr, mine)
+        tot = mine.clone()
+        dist.all_reduce(tot)
+        if tdev != "cpu":
+            torch.cuda.synchronize()
+        ok = bool(torch.equal(allr.view(world, 1024)[:, 0].cpu(), torch.arange(world, dtype=torch.float64))) and float(tot[0].item()) == world * (world - 1) / 2.0
+    if not ok:
+        raise SystemExit("bench.py: rank %d: the collective self-test returned wrong data" % rank)
+    return {"ok": ok, "world": dist.get_world_size(), "ms": stg.elapsed * 1e3, "what": "all_gather_into_tensor of the rank ids + all_reduce(sum) on the run's own communicator"}
+
+
+def exchange_map_hash(torch, dist, rank, world, tdev, map_hash):
+    """every rank's hash of its gathered grid, all-gathered and compared: a rank that holds another grid ends the job"""
+    with Stage("map hash exchange", 120, rank):
+        hv = torch.tensor([int(map_hash, 16)], dtype=torch.int64, device=tdev)
+        hall = torch.empty(world, dtype=torch.int64, device=tdev)
+        dist.all_gather_into_tensor(hall, hv)
+        if tdev != "cpu":
+            torch.cuda.synchronize()
+    if not bool((hall == hall[0]).all().item()):
+        raise SystemExit("bench.py: rank %d: the gathered map differs between ranks (%s)" % (rank, [hex(int(v)) for v in hall.tolist()]))
+    return True
+
+
+def gather_times(torch, dist, world, tdev, dt, steps):
+    """per-rank step times (reporting) and the MAX over the ranks (the job's time)"""
+    mine = torch.tensor([dt], dtype=torch.float64, device=tdev)
+    allt = torch.empty(world, dtype=torch.float64, device=tdev)
+    dist.all_gather_into_tensor(allt, mine)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return [float(v) / steps * 1e3 for v in allt.tolist()], float(tmax.item())
+
+
+def dry_distributed(args):
+    """UPH_BENCH_DRY_DIST=1 under a launcher (CPU tier, tests/test_dist_cpu.py): the rank handshake of an N-GPU run -- world == --gpus, the collective self-test, the
+    map-hash exchange, the barrier-bracketed timing reduction -- over gloo on CPU tensors, no device touched: the Python of the N > 1 path runs for worlds 2 .. 8 before
+    it ever meets eight GPUs.  UPH_BENCH_DRY_BAD_RANK=r makes rank r hold another grid (the job must fail)."""
+    import datetime
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world and the flag disagree" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    with Stage("rendezvous", 120, rank):
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+    st = dist_selftest(torch, dist, rank, world, "cpu")
+    cells = np.arange(4096, dtype=np.float64) + (1.0 if os.environ.get("UPH_BENCH_DRY_BAD_RANK") == str(rank) else 0.0)
+    h = hashlib.sha1(cells.tobytes()).hexdigest()[:15]
+    same = exchange_map_hash(torch, dist, rank, world, "cpu", h)
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + rank))
+    dist.barrier()
+    per_rank, dt = gather_times(torch, dist, world, "cpu", time.perf_counter() - t0, args.steps)
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_selftest": st, "map_hash": h, "map_hash_identical_on_all_ranks": same, "per_rank_ms_per_step": per_rank,
+                          "per_rank_spread": (max(per_rank) - min(per_rank)) / max(per_rank), "ms_per_step": dt / args.steps * 1e3}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -590,6 +658,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
         spawn_ranks(args.gpus, sys.argv[1:])
         return
+    if os.environ.get("UPH_BENCH_DRY_DIST") == "1" and "WORLD_SIZE" in os.environ and not args.single_process:
+        return dry_distributed(args)
     if args.single_process:
         if os.environ.get("UPH_BENCH_SPAWN_ECHO") == "1":
             return single_process_dry_run(args)
@@ -623,18 +693,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: RCCL world of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
-        # collective self-test before anything is measured: an all-gather of the rank ids and a sum with known answers over the communicator the run will use
-        with Stage("RCCL self-test", 120, rank) as stg:
-            mine = torch.full((1024,), float(rank), dtype=torch.float64, device="cuda")
-            allr = torch.empty(1024 * world, dtype=torch.float64, device="cuda")
-            dist.all_gather_into_tensor(allr, mine)
-            tot = mine.clone()
-            dist.all_reduce(tot)
-            torch.cuda.synchronize()
-            ok = bool(torch.equal(allr.view(world, 1024)[:, 0].cpu(), torch.arange(world, dtype=torch.float64))) and float(tot[0].item()) == world * (world - 1) / 2.0
-        selftest = {"ok": ok, "world": dist.get_world_size(), "ms": stg.elapsed * 1e3, "what": "all_gather_into_tensor of the rank ids + all_reduce(sum) on the run's own communicator"}
-        if not ok:
-            raise SystemExit("bench.py: rank %d: the RCCL self-test returned wrong data" % rank)
+        selftest = dist_selftest(torch, dist, rank, world, "cuda")
     device = local_rank if distributed else 0
     torch.cuda.set_device(device)
 
@@ -674,14 +733,7 @@ def main():
         import hashlib
         map_hash = hashlib.sha1(np.ascontiguousarray(m.map_buffer).tobytes()).hexdigest()[:15]
         if distributed:
-            with Stage("map hash exchange", 120, rank):
-                hv = torch.tensor([int(map_hash, 16)], dtype=torch.int64, device="cuda")
-                hall = torch.empty(world, dtype=torch.int64, device="cuda")
-                dist.all_gather_into_tensor(hall, hv)
-                torch.cuda.synchronize()
-            map_hash_same = bool((hall == hall[0]).all().item())
-            if not map_hash_same:
-                raise SystemExit("bench.py: rank %d: the gathered map differs between ranks (%s)" % (rank, [hex(int(v)) for v in hall.tolist()]))
+            map_hash_same = exchange_map_hash(torch, dist, rank, world, "cuda", map_hash)
 
     # ---- problems, free cells only: config-3 protocol on the hill map; local goals (4..14 m) over the whole square for km2
     nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
@@ -920,13 +972,7 @@ def main():
         dt = time.perf_counter() - t0
     per_rank_ms = [dt / args.steps * 1e3]
     if distributed:
-        mine = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        allt = torch.empty(world, dtype=torch.float64, device="cuda")
-        dist.all_gather_into_tensor(allt, mine)                      # (reporting only: outside the timed region)
-        per_rank_ms = [float(v) / args.steps * 1e3 for v in allt.tolist()]
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        per_rank_ms, dt = gather_times(torch, dist, world, "cuda", dt, args.steps)      # (reporting + the MAX over the ranks: outside the timed region)
 
     out = opt.download(full=False)
     rets = np.array([o["ret"] for o in out])

@@ -185,3 +185,29 @@ def test_bench_single_process_dry_run_for_8_gpus():
         assert line["config"]["parallelism"] == "dp%d" % n and line["config"]["rccl_world"] == n and len(line["per_rank_ms_per_step"]) == n == len(line["per_gpu_kernel_ms"])
         d = line["dry_run"]
         assert d["all_gather_in_place"] == inplace and d["slabs"][-1] == last and len(d["slabs"]) == n and d["seed0_per_device"] == [1000 + 512 * g for g in range(n)]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_rank_handshake_dry_run_over_gloo(world):
+    """the Python of bench.py's N > 1 path -- world == --gpus, the collective self-test with known answers, the all-gathered map hash, the
+    MAX-over-ranks timing -- run for worlds of 2 and 8 over gloo on CPU tensors (UPH_BENCH_DRY_DIST=1: the same helper functions the real run calls, no device),
+    self-spawned ranks (bench.spawn_ranks).  A rank that holds another grid must end the job with a non-zero exit, and so must a launcher world that is not --gpus."""
+    import json
+    import subprocess
+    base = dict(os.environ, UPH_BENCH_DRY_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "UPH_BENCH_SPAWN_ECHO", "UPH_BENCH_DRY_BAD_RANK"):
+        base.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2"], capture_output=True, text=True, env=base, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == world and line["rccl_selftest"]["ok"] and line["rccl_selftest"]["world"] == world
+    assert line["map_hash_identical_on_all_ranks"] is True and len(line["per_rank_ms_per_step"]) == world
+    # the job's time is the slowest rank's (rank r sleeps 10 (1 + r) ms between the barriers)
+    assert abs(line["ms_per_step"] - max(line["per_rank_ms_per_step"])) < 1e-9 and line["ms_per_step"] >= 10.0 * world / 2 * 0.9
+    if world == 2:
+        bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=dict(base, UPH_BENCH_DRY_BAD_RANK="1"), timeout=300)
+        assert bad.returncode != 0 and "differs between ranks" in bad.stderr
+        # a launcher whose world is not --gpus: refused by every rank
+        env2 = dict(base, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+        mm = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True, text=True, env=env2, timeout=120)
+        assert mm.returncode != 0 and "disagree" in (mm.stderr + mm.stdout)

@@ -213,6 +213,17 @@ r = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
 print("fp32 samples value %.0f dtype %s pipelined %s traffic_source %s" % (r["value"], r["dtype"], r.get("pipelined"), r["roofline"]["traffic_source"][:90]))
 PY
 ;;
+14)
+# after the handshake refactor: the RCCL path with one rank, and the plain default line (short)
+OUT=gpurun_out/r06m; mkdir -p $OUT; export TMPDIR=/tmp
+UPH_FORCE_DIST=1 MASTER_PORT=29517 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 600 python bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu --no-extras > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "dist1 rc $?"; tail -2 $OUT/bench_dist1.err
+python - $OUT/bench_dist1.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+print("dist1:", r["value"], r["rccl_selftest"], r["map_hash"], r["map_hash_identical_on_all_ranks"], r["config"]["rccl_world"], r["per_rank_spread"])
+PY
+timeout 600 python bench.py --steps 3 --warmup 1 --no-configs > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?"; tail -c 300 $OUT/bench.json
+;;
 6)
 # end-of-round record on the final sources: smoke, the whole GPU tier, profile.sh (bench line, kernel trace, counter passes, calibration) for the headline and for --workload astar
 OUT=gpurun_out/r06z; mkdir -p $OUT
