@@ -4,7 +4,7 @@ For N random hill-cloud problems and a few parameter sets (the shipped run_hill.
 per ALM pass, which yields short solves), three solvers run on identical inputs: the CPU oracle, the same oracle rebuilt with FMA
 contraction (the reference's own reproducibility floor: ~1 ulp per operation, nothing else changed) and the device.  Rows = buckets
 of the oracle's total L-BFGS iteration count; columns = fraction of problems whose final way-points / cost agree with the oracle
-to 1e-4 (relative, infinity norm) and the median deviation.  usage: python tools/parity_buckets.py [N] [out.json] [hill|desert|vocano]
+to 1e-4 (relative, infinity norm) and the median deviation.  usage: python tools/parity_buckets.py [N] [out.json] [hill|desert|vocano|astar]
 (desert / vocano: the reference's own clouds, fixtures tests/golden/*_xyz.npz, run_hill.yaml / run_vocano.yaml parameters only)"""
 import json
 import os
@@ -29,7 +29,9 @@ def main():
     global PARAM_SETS
     if os.environ.get("UPH_PB_ONLY_YAML"):           # the shipped parameter set only (large-N drift statistics)
         PARAM_SETS = PARAM_SETS[:1]
-    if scene == "hill":
+    if scene in ("hill", "astar"):
+        if scene == "astar":
+            PARAM_SETS = PARAM_SETS[:1]
         m = U.UnevenMap()
         m.build(scenes.make_hill_cloud())
     else:
@@ -37,7 +39,14 @@ def main():
         m = U.UnevenMap(dict(max_rho=0.08) if scene == "vocano" else None)        # run_vocano.yaml differs in max_rho only
         m.build(np.load(os.path.join(os.getcwd(), "tests", "golden", "%s_xyz.npz" % scene))["xyz"])
     nx, ny = int(m.voxel_num[0]), int(m.voxel_num[1])
-    probs = scenes.random_problems(N, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
+    if scene == "astar":
+        # round 6: the A*-seeded workload of `bench.py --workload astar` -- the problems the reference's own chain produces (device KinoAstar::plan + PlanManager's resampling)
+        sys.path.insert(0, os.getcwd())
+        import bench
+        probs, meta = bench.astar_batch(U, scenes, m, (nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]), N, 1000)
+        print("A*-seeded problems:", meta)
+    else:
+        probs = scenes.random_problems(N, seed0=1000, occ_r2=m.occ_r2_buffer, grid=(nx, ny, m.xy_resolution, m.map_origin[0], m.map_origin[1]))
     og = O.OracleGrid()
     og.set_cells(m.map_buffer)
     report = {}

@@ -224,6 +224,11 @@ print("dist1:", r["value"], r["rccl_selftest"], r["map_hash"], r["map_hash_ident
 PY
 timeout 600 python bench.py --steps 3 --warmup 1 --no-configs > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?"; tail -c 300 $OUT/bench.json
 ;;
+15)
+# parity buckets + drift statistics of the A*-seeded workload at N = 2048 (device | oracle(FMA) against the oracle), all host threads for the two CPU legs
+OUT=gpurun_out/r06n; mkdir -p $OUT
+UPH_PB_THREADS=$(nproc) timeout 1500 python tools/parity_buckets.py 2048 $OUT/parity_buckets_astar_2048.json astar 2>&1 | grep -v amdgpu.ids | tee $OUT/parity_buckets_astar_2048.txt | tail -14
+;;
 6)
 # end-of-round record on the final sources: smoke, the whole GPU tier, profile.sh (bench line, kernel trace, counter passes, calibration) for the headline and for --workload astar
 OUT=gpurun_out/r06z; mkdir -p $OUT
