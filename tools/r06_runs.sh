@@ -229,6 +229,22 @@ timeout 600 python bench.py --steps 3 --warmup 1 --no-configs > $OUT/bench.json 
 OUT=gpurun_out/r06n; mkdir -p $OUT
 UPH_PB_THREADS=$(nproc) timeout 1500 python tools/parity_buckets.py 2048 $OUT/parity_buckets_astar_2048.json astar 2>&1 | grep -v amdgpu.ids | tee $OUT/parity_buckets_astar_2048.txt | tail -14
 ;;
+16)
+# the last commit: smoke, the whole GPU tier, the driver's form of the bench call
+OUT=gpurun_out/r06zz; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $OUT/smoke.txt
+timeout 1200 python -m pytest tests -x -q -m gpu > $OUT/gpu_tests.txt 2>&1; echo "all rc $?" >> $OUT/gpu_tests.txt
+tail -3 $OUT/gpu_tests.txt | cut -c1-300
+( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real | tee $OUT/bench_wall.txt; tail -2 $OUT/bench.err
+python - $OUT/bench.json <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+rf = r["roofline"]
+print("value %.0f  ms/step %.2f  launch %.1f ms  frac %.3f  converged %.3f | penalty %s | traffic %.4g (%s)" % (r["value"], r["ms_per_step"], rf["avg_launch_ms"], rf["frac"], r["converged_frac"],
+      {k: round(v, 3) for k, v in rf["penalty_kernel"].items() if k.startswith("frac")}, rf["traffic"] or 0, rf["traffic_source"][:50]))
+print("configs:", [(round(e.get("value", -1), 1), e.get("error", "")) for e in r["configs"]["entries"]], "astar extra %.0f" % r.get("traj_opts_per_s_astar_seeded", 0))
+PY
+;;
 6)
 # end-of-round record on the final sources: smoke, the whole GPU tier, profile.sh (bench line, kernel trace, counter passes, calibration) for the headline and for --workload astar
 OUT=gpurun_out/r06z; mkdir -p $OUT
