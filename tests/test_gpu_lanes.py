@@ -75,6 +75,41 @@ def test_variant_evaluation_scaling_and_solve(dev, oracle, oracle_grid, hill_pro
         assert out[i]["ret"] == ro["ret"] or max(out[i]["alm_iters"], ro["alm_iters"]) >= 9
 
 
+@pytest.mark.parametrize("lanes", [64, 128, 256, 512])
+def test_penalty_kernel_alone_for_every_lane_count(dev, oracle, oracle_grid, hill_problem, small_problems, lanes):
+    """uph_penalty_batch (calConstrainCostGrad alone, kernel MODE 8) in each of its four instantiations -- <128,2,8> is the one bench.py times for
+    roofline.penalty_kernel.frac_a5_only -- against the oracle's function: cost, gdCxy, gdCyaw, the two gdT sums, hx, gx at 1e-9"""
+    import uneven_planner_amd as U
+    opt = U.ALMTrajOpt(dev)
+    opt.set_lanes(lanes)
+    probs = [hill_problem] + small_problems
+    rng = np.random.default_rng(23)
+    lam, mu, sc = [], [], []
+    for p in probs:
+        S = (p["inner_xy"].shape[1] + 1) * 17
+        lam.append(rng.normal(size=S) * 0.1)
+        mu.append(np.abs(rng.normal(size=6 * S)) * 0.1 * (rng.uniform(size=6 * S) < 0.7))
+        sc.append(rng.uniform(0.2, 1.0, size=7 * S))
+    sfx = rng.uniform(0.1, 1.0, size=len(probs))
+    opt.upload(probs)
+    opt.set_state(lam=lam, mu=mu, scale_cx=sc, scale_fx=sfx, rho=np.full(len(probs), 2.0))
+    opt.eval_batch(opt.x0_packed(probs))
+    got = opt.penalty_batch(repeat=2, store_residuals=True)
+    out = opt.download()
+    for i, p in enumerate(probs):
+        a = oracle.OracleALM(oracle_grid)
+        x0 = a.setup(p)
+        a.set_state(lam=lam[i], mu=mu[i], scale_cx=sc[i], scale_fx=sfx[i])
+        a.set_rho(2.0)
+        cost, gcx, gtx, gcy, gty = a.constrain(x0)
+        st = a.get_state()
+        d = got[i]
+        assert abs(d["cost"] - cost) / abs(cost) < 1e-9
+        assert rel(gcx, d["gdCxy"]) < 1e-9 and rel(gcy, d["gdCyaw"]) < 1e-9
+        assert abs(d["gdTxy_sum"] - gtx.sum()) / max(1e-300, np.abs(gtx).sum()) < 1e-9 and abs(d["gdTyaw_sum"] - gty.sum()) / max(1e-300, np.abs(gty).sum()) < 1e-9
+        assert rel(st["hx"], out[i]["hx"]) < 1e-9 and rel(st["gx"], out[i]["gx"]) < 1e-9
+
+
 def test_large_batch_takes_the_128_lane_path_and_matches_the_oracle(dev, oracle, oracle_grid, analytic_cells):
     """B = 2400 (>= 2304) selects <128,2,2>, the kernel bench.py times: sampled trajectories against the oracle"""
     import uneven_planner_amd as U
