@@ -1081,6 +1081,9 @@ def main():
                          "valu_busy_source": ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch x 2.4 GHz) of the counter pass: %s (git %s, kernel sources %s, launch %.1f ms)" % (
                              pc.get("tag"), pc.get("git_head"), pc.get("kernel_src_sha"), pc.get("launch_ms", float("nan")))) if pc is not None else pc_why,
                          "kernel_src_sha": kernel_sources_sha()},
+            # which library ran: the hash compiled into libunevenhip.so against the same hash of the tree's sources (csrc/Makefile, _lib.sources_id)
+            "library": {"build_id": U._lib.build_id(), "sources_id": U._lib.sources_id(), "is_a_build_of_this_tree": U._lib.build_id() == U._lib.sources_id(),
+                        "path": os.environ.get("UNEVENHIP_LIB") or os.path.join(ROOT, "uneven_planner_amd", "libunevenhip.so")},
         }
         if astar_wl:
             res["metric"] = "MINCO traj-opts/sec (batch), A*-seeded inputs"

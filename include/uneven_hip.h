@@ -192,6 +192,9 @@ typedef struct uph_result {
 const char* uph_last_error(void);
 int uph_device_count(void);
 const char* uph_version(void);
+/* hash (16 hex digits) of the sources this library was built from: every .hip / .hpp / .cpp file of csrc and this header, in sorted order (csrc/Makefile) --
+ * `uneven_planner_amd._lib.sources_id()` computes the same over the tree, so a run can tell whether the library it loaded is a build of the tree next to it */
+const char* uph_build_id(void);
 
 /* ---- initial guess: PlanManager::rcvWpsCallBack between kino_astar->plan and traj_opt.optimizeSE2Traj (plan_manager.cpp:62-132) -- or, with
  *      mp->test_mode, the test node's ALMTrajOpt::rcvWpsCallBack (alm_traj_opt.cpp:73-144) --, for a

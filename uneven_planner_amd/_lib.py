@@ -129,6 +129,7 @@ SYMBOLS = {
     "uph_batch_stats": (C.c_int, [_VP, DP, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
     "uph_batch_prepare_ms": (C.c_int, [_VP, DP]),
     "uph_batch_cycles": (C.c_int, [_VP, C.POINTER(C.c_longlong)]),
+    "uph_build_id": (C.c_char_p, []),
     "uph_eval_batch": (C.c_int, [_VP, DP, DP, DP, _I32]),
     "uph_penalty_batch": (C.c_int, [_VP, _I32, _I32, DP, DP, DP, DP]),
     "uph_init_scaling_batch": (C.c_int, [_VP]),
@@ -185,6 +186,26 @@ def load():
             fn.argtypes = args
         _LIB = L
     return _LIB
+
+
+def sources_id():
+    """the hash csrc/Makefile compiles into the library (uph_build_id), computed over the tree: csrc/*.hip, *.hpp, *.cpp sorted by name, then include/uneven_hip.h"""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".cpp")))
+    h = hashlib.sha1()
+    for f in files:
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(here, "..", "include", "uneven_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_id():
+    L = load()
+    return L.uph_build_id().decode() if hasattr(L, "uph_build_id") else None
 
 
 def check(rc, what=""):
